@@ -1,0 +1,197 @@
+"""Device-side exact-GP plan: torch owns memory and streams, libdgp_hip.so does the arithmetic.
+
+``GPPlan`` is the thin host object the engine (``discontinuum_amd.engines.hip``) drives; it is the
+MI355X replacement for what gpytorch's ``ExactGP`` + ``ExactMarginalLogLikelihood`` +
+``DefaultPredictionStrategy`` do underneath the reference loop
+(``src/discontinuum/engines/gpytorch.py:318, 350-384, 599-626``).  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+MODELS = {"loadest": _lib.MODEL_LOADEST, "rating": _lib.MODEL_RATING}
+_DTYPES = {torch.float64: _lib.F64, torch.float32: _lib.F32}
+
+
+def _theta_array(theta, ntheta):
+    if torch.is_tensor(theta):
+        theta = theta.detach().to("cpu", torch.float64).reshape(-1).tolist()
+    vals = [float(v) for v in theta]
+    if len(vals) != ntheta:
+        raise ValueError(f"expected {ntheta} kernel hyperparameters, got {len(vals)}")
+    return (C.c_double * ntheta)(*vals)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class GPPlan:
+    """Fixed (model, dtype, n, d) exact-GP problem resident on one GPU."""
+
+    def __init__(self, model: str, n: int, d: int, dtype=torch.float64, device="cuda", lookahead=True):
+        if model not in MODELS:
+            raise ValueError(f"unknown model {model!r}; expected one of {sorted(MODELS)}")
+        if dtype not in _DTYPES:
+            raise ValueError("dtype must be torch.float64 or torch.float32")
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("discontinuum_amd requires a ROCm GPU (MI355X); there is no CPU fallback")
+        self.model, self.n, self.d, self.dtype = model, int(n), int(d), dtype
+        self.device = torch.device(device)
+        self.ntheta = self.lib.dgp_model_ntheta(MODELS[model], self.d)
+        if self.ntheta < 0:
+            raise ValueError(f"model {model!r} does not support d={d}")
+        self.N = int(self.lib.dgp_padded_n(self.n))
+        handle = C.c_void_p()
+        _lib.check(self.lib.dgp_plan_create(MODELS[model], _DTYPES[dtype], self.n, self.d, C.byref(handle)), "dgp_plan_create")
+        self._h = handle
+        nbytes = int(self.lib.dgp_plan_workspace_bytes(self._h))
+        with torch.cuda.device(self.device):
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            off = (-self._ws.data_ptr()) % 256
+            self._ws_off = off
+            _lib.check(
+                self.lib.dgp_plan_set_workspace(self._h, C.c_void_p(self._ws.data_ptr() + off), nbytes),
+                "dgp_plan_set_workspace",
+            )
+            self._pred_ws = None
+        self.set_lookahead(lookahead)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:  # noqa: BLE001
+                pass
+            self.lib.dgp_plan_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------ helpers
+    def set_lookahead(self, enabled: bool):
+        _lib.check(self.lib.dgp_plan_set_lookahead(self._h, int(bool(enabled))), "dgp_plan_set_lookahead")
+
+    def _check_vec(self, t, name, length=None):
+        length = self.n if length is None else length
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == self.dtype and t.is_contiguous() and t.numel() == length):
+            raise ValueError(f"{name} must be a contiguous {self.dtype} CUDA tensor with {length} elements")
+
+    def buffer(self, which: int) -> torch.Tensor:
+        """Tensor view of a plan buffer (tests / profiling)."""
+        p, ld = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.dgp_plan_buffer(self._h, which, C.byref(p), C.byref(ld)), "dgp_plan_buffer")
+        esz = torch.empty((), dtype=self.dtype).element_size()
+        off = p.value - self._ws.data_ptr()
+        N = self.N
+        count = {_lib.BUF_XT: self.d * N, _lib.BUF_Z: N, _lib.BUF_ALPHA: N}.get(which, N * N)
+        flat = self._ws[off:off + count * esz].view(self.dtype)
+        if which == _lib.BUF_XT:
+            return flat.view(self.d, N)
+        return flat if count == N else flat.view(N, N)
+
+    # ------------------------------------------------------------------ hot path
+    def set_inputs(self, X: torch.Tensor):
+        self._check_vec(X, "X", self.n * self.d)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dgp_set_inputs(self._h, _ptr(X), _stream()), "dgp_set_inputs")
+        self._X = X  # keep alive until the async pack has certainly run
+
+    def fit_step(self, theta, r: torch.Tensor, noise: torch.Tensor):
+        """-> (out[32], alpha[n], dnoise[n]) device tensors; see include/dgp_hip.h DGP_OUT_*."""
+        self._check_vec(r, "r")
+        self._check_vec(noise, "noise")
+        th = _theta_array(theta, self.ntheta)
+        with torch.cuda.device(self.device):
+            out = torch.empty(_lib.OUT_LEN, dtype=self.dtype, device=self.device)
+            dr = torch.empty(self.n, dtype=self.dtype, device=self.device)
+            dnoise = torch.empty(self.n, dtype=self.dtype, device=self.device)
+            _lib.check(
+                self.lib.dgp_fit_step(self._h, th, _ptr(r), _ptr(noise), _ptr(out), _ptr(dr), _ptr(dnoise), _stream()),
+                "dgp_fit_step",
+            )
+        return out, dr, dnoise
+
+    def factorize(self, theta, r: torch.Tensor, noise: torch.Tensor):
+        self._check_vec(r, "r")
+        self._check_vec(noise, "noise")
+        th = _theta_array(theta, self.ntheta)
+        with torch.cuda.device(self.device):
+            out = torch.empty(_lib.OUT_LEN, dtype=self.dtype, device=self.device)
+            _lib.check(self.lib.dgp_factorize(self._h, th, _ptr(r), _ptr(noise), _ptr(out), _stream()), "dgp_factorize")
+        return out
+
+    def predict(self, theta, Xs: torch.Tensor, chunk: int = 4096):
+        """Latent posterior (K*^T alpha, diag(K** - K*^T K^^-1 K*)) at Xs (m, d) from the held factorisation."""
+        if not (torch.is_tensor(Xs) and Xs.is_cuda and Xs.dtype == self.dtype and Xs.dim() == 2 and Xs.shape[1] == self.d):
+            raise ValueError(f"Xs must be a (m, {self.d}) {self.dtype} CUDA tensor")
+        th = _theta_array(theta, self.ntheta)
+        m = Xs.shape[0]
+        mean = torch.empty(m, dtype=self.dtype, device=self.device)
+        var = torch.empty(m, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            for lo in range(0, m, chunk):
+                hi = min(lo + chunk, m)
+                xs = Xs[lo:hi].contiguous()
+                need = int(self.lib.dgp_predict_workspace_bytes(self._h, hi - lo))
+                if self._pred_ws is None or self._pred_ws.numel() < need + 256:
+                    self._pred_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+                base = self._pred_ws.data_ptr()
+                base += (-base) % 256
+                _lib.check(
+                    self.lib.dgp_predict(
+                        self._h, th, _ptr(xs), hi - lo, C.c_void_p(base), need, _ptr(mean[lo:hi]), _ptr(var[lo:hi]), _stream()
+                    ),
+                    "dgp_predict",
+                )
+        return mean, var
+
+    # ------------------------------------------------------------------ single stages (tests, profiling)
+    def stage_gram(self, theta, noise):
+        self._check_vec(noise, "noise")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dgp_stage_gram(self._h, _theta_array(theta, self.ntheta), _ptr(noise), _stream()), "dgp_stage_gram")
+
+    def stage_potrf(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dgp_stage_potrf(self._h, _stream()), "dgp_stage_potrf")
+
+    def stage_trtri(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dgp_stage_trtri(self._h, _stream()), "dgp_stage_trtri")
+
+    def stage_lauum(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dgp_stage_lauum(self._h, _stream()), "dgp_stage_lauum")
+
+    def stage_solve(self, r):
+        self._check_vec(r, "r")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dgp_stage_solve(self._h, _ptr(r), _stream()), "dgp_stage_solve")
+
+    def stage_grad(self, theta):
+        with torch.cuda.device(self.device):
+            out = torch.zeros(_lib.OUT_LEN, dtype=self.dtype, device=self.device)
+            _lib.check(self.lib.dgp_stage_grad(self._h, _theta_array(theta, self.ntheta), _ptr(out), _stream()), "dgp_stage_grad")
+        return out[: self.ntheta]
+
+    def cross_gram(self, theta, Xs):
+        m = Xs.shape[0]
+        M = int(self.lib.dgp_padded_n(m))
+        with torch.cuda.device(self.device):
+            work = torch.empty(self.d * M, dtype=self.dtype, device=self.device)
+            Ks = torch.empty(self.N, M, dtype=self.dtype, device=self.device)
+            xs = Xs.contiguous()
+            _lib.check(
+                self.lib.dgp_cross_gram(self._h, _theta_array(theta, self.ntheta), _ptr(xs), m, _ptr(work), _ptr(Ks), _stream()),
+                "dgp_cross_gram",
+            )
+        return Ks[: self.n, :m]

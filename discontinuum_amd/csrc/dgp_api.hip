@@ -1,0 +1,364 @@
+// dgp_api.hip -- the C ABI declared in include/dgp_hip.h: plan bookkeeping and stage sequencing.
+#include <new>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dgp_hip.h"
+#include "dgp_internal.h"
+
+using namespace dgp;
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+static int hipfail(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return (int)e;
+}
+
+struct dgp_plan {
+  int model, dtype, d, ntheta;
+  int64_t n, N;
+  size_t elem;
+  char* ws;
+  size_t ws_bytes;
+  // carved workspace
+  void *Xt, *A, *Tm, *S, *z, *alpha, *gpart, *spart, *scal;
+  int* info;
+  int lookahead;
+  int have_inputs, have_factor;
+  hipStream_t s2;
+  hipEvent_t* ev;
+  int nev;
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+  size_t Xt, A, Tm, S, z, alpha, gpart, spart, scal, info, total;
+};
+static Layout layout(const dgp_plan* p) {
+  Layout L;
+  const size_t e = p->elem, N = (size_t)p->N;
+  size_t o = 0;
+  L.Xt = o; o += align_up(e * N * p->d);
+  L.A = o; o += align_up(e * N * N);
+  L.Tm = o; o += align_up(e * N * N);
+  L.S = o; o += align_up(e * N * N);
+  L.z = o; o += align_up(e * N);
+  L.alpha = o; o += align_up(e * N);
+  L.gpart = o; o += align_up(e * (size_t)gram_grad_partials(p->N));
+  L.spart = o; o += align_up(e * (size_t)solve_partials(p->N));
+  L.scal = o; o += align_up(e * 16);
+  L.info = o; o += align_up(sizeof(int) * 4);
+  L.total = o;
+  return L;
+}
+
+extern "C" {
+
+int dgp_version(void) { return 1; }
+const char* dgp_last_error(void) { return g_err; }
+int dgp_model_ntheta(int model, int d) { return model_ntheta(model, d); }
+int64_t dgp_padded_n(int64_t n) { return round_up(n, DGP_TILE_HOST); }
+
+int dgp_plan_create(int model, int dtype, int64_t n, int d, dgp_plan** out) {
+  if (!out || n <= 0 || n > (1 << 20)) return fail(DGP_E_ARG, "dgp_plan_create: bad n / null out");
+  if (dtype != DGP_F64 && dtype != DGP_F32) return fail(DGP_E_ARG, "dgp_plan_create: dtype must be 0 (f64) or 1 (f32)");
+  const int nt = model_ntheta(model, d);
+  if (nt < 0) return fail(DGP_E_MODEL, "dgp_plan_create: unsupported (model, d)");
+  dgp_plan* p = new (std::nothrow) dgp_plan();
+  if (!p) return fail(DGP_E_ARG, "dgp_plan_create: out of host memory");
+  memset(p, 0, sizeof(*p));
+  p->model = model;
+  p->dtype = dtype;
+  p->d = d;
+  p->ntheta = nt;
+  p->n = n;
+  p->N = round_up(n, DGP_TILE_HOST);
+  p->elem = dtype == DGP_F64 ? 8 : 4;
+  p->lookahead = 1;
+  *out = p;
+  return 0;
+}
+
+int dgp_plan_destroy(dgp_plan* p) {
+  if (!p) return 0;
+  if (p->ev) {
+    for (int i = 0; i < p->nev; ++i) (void)hipEventDestroy(p->ev[i]);
+    delete[] p->ev;
+  }
+  if (p->s2) (void)hipStreamDestroy(p->s2);
+  delete p;
+  return 0;
+}
+
+size_t dgp_plan_workspace_bytes(const dgp_plan* p) { return p ? layout(p).total : 0; }
+
+int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
+  if (!p || !dev_ptr) return fail(DGP_E_ARG, "dgp_plan_set_workspace: null");
+  const Layout L = layout(p);
+  if (bytes < L.total) return fail(DGP_E_WORKSPACE, "dgp_plan_set_workspace: workspace too small");
+  if (((uintptr_t)dev_ptr & 255) != 0) return fail(DGP_E_ARG, "dgp_plan_set_workspace: pointer must be 256-byte aligned");
+  p->ws = (char*)dev_ptr;
+  p->ws_bytes = bytes;
+  p->Xt = p->ws + L.Xt;
+  p->A = p->ws + L.A;
+  p->Tm = p->ws + L.Tm;
+  p->S = p->ws + L.S;
+  p->z = p->ws + L.z;
+  p->alpha = p->ws + L.alpha;
+  p->gpart = p->ws + L.gpart;
+  p->spart = p->ws + L.spart;
+  p->scal = p->ws + L.scal;
+  p->info = (int*)(p->ws + L.info);
+  p->have_inputs = p->have_factor = 0;
+  return 0;
+}
+
+int dgp_plan_set_lookahead(dgp_plan* p, int enabled) {
+  if (!p) return fail(DGP_E_ARG, "null plan");
+  p->lookahead = enabled ? 1 : 0;
+  return 0;
+}
+
+int dgp_plan_buffer(const dgp_plan* p, int which, void** dev_ptr, int64_t* ld) {
+  if (!p || !dev_ptr || !p->ws) return fail(DGP_E_ARG, "dgp_plan_buffer: null / no workspace");
+  void* q = nullptr;
+  switch (which) {
+    case DGP_BUF_XT: q = p->Xt; break;
+    case DGP_BUF_A: q = p->A; break;
+    case DGP_BUF_T: q = p->Tm; break;
+    case DGP_BUF_S: q = p->S; break;
+    case DGP_BUF_Z: q = p->z; break;
+    case DGP_BUF_ALPHA: q = p->alpha; break;
+    default: return fail(DGP_E_ARG, "dgp_plan_buffer: unknown buffer");
+  }
+  *dev_ptr = q;
+  if (ld) *ld = p->N;
+  return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+static int ensure_async(dgp_plan* p) {
+  if (!p->lookahead || p->s2) return 0;
+  hipError_t e = hipStreamCreateWithFlags(&p->s2, hipStreamNonBlocking);
+  if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithFlags");
+  p->nev = 2 * (int)(p->N / DGP_TILE_HOST);
+  p->ev = new (std::nothrow) hipEvent_t[p->nev];
+  if (!p->ev) return fail(DGP_E_ARG, "out of host memory");
+  for (int i = 0; i < p->nev; ++i) {
+    e = hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) return hipfail(e, "hipEventCreateWithFlags");
+  }
+  return 0;
+}
+
+template <typename T>
+__global__ void assemble_kernel(const T* scal, const int* info, long n, int ntheta, int zero_grad, T* out) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    const T logdet = scal[0], quad = scal[1];
+    out[DGP_OUT_NLL] = T(0.5) * quad + T(0.5) * logdet + T(0.5 * 1.83787706640934548356) * (T)n;
+    out[DGP_OUT_QUAD] = quad;
+    out[DGP_OUT_LOGDET] = logdet;
+    out[DGP_OUT_INFO] = (T)info[0];
+  }
+  if (zero_grad && t >= DGP_OUT_DTHETA && t < DGP_OUT_LEN) out[t] = T(0);
+  if (!zero_grad && t >= DGP_OUT_DTHETA + ntheta && t < DGP_OUT_LEN) out[t] = T(0);
+}
+
+template <typename T>
+__global__ void copy_n_kernel(const T* src, long n, T* dst) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+template <typename T>
+static int run_gram(dgp_plan* p, const double* theta, const void* noise, hipStream_t s) {
+  return gram_sym<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)noise, (T*)p->A, s);
+}
+template <typename T>
+static int run_potrf(dgp_plan* p, hipStream_t s) {
+  int rc = ensure_async(p);
+  if (rc) return rc;
+  return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, p->lookahead, s, p->s2, p->ev);
+}
+template <typename T>
+static int run_trtri(dgp_plan* p, hipStream_t s) {
+  return trtri<T>((const T*)p->A, nullptr, p->N, (T*)p->Tm, (T*)p->S /* scratch W aliases S */, s);
+}
+template <typename T>
+static int run_lauum(dgp_plan* p, hipStream_t s) {
+  return lauum<T>((const T*)p->Tm, p->N, (T*)p->S, s);
+}
+template <typename T>
+static int run_solve(dgp_plan* p, const void* r, hipStream_t s) {
+  return solve<T>((const T*)p->Tm, p->N, (const T*)r, (int)p->n, (T*)p->z, (T*)p->alpha, (T*)p->spart,
+                  (T*)p->scal + 1, s);
+}
+template <typename T>
+static int run_grad(dgp_plan* p, const double* theta, void* dtheta, hipStream_t s) {
+  return gram_grad<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)p->S, (const T*)p->alpha,
+                      (T*)p->gpart, (T*)dtheta, s);
+}
+
+template <typename T>
+static int fit_step(dgp_plan* p, const double* theta, const void* r, const void* noise, void* out, void* dr,
+                    void* dnoise, int with_grad, hipStream_t s) {
+  int rc;
+  if ((rc = run_gram<T>(p, theta, noise, s))) return rc;
+  if ((rc = run_potrf<T>(p, s))) return rc;
+  if ((rc = run_trtri<T>(p, s))) return rc;
+  if ((rc = run_solve<T>(p, r, s))) return rc;
+  if (with_grad) {
+    if ((rc = run_lauum<T>(p, s))) return rc;
+    if ((rc = run_grad<T>(p, theta, (T*)out + DGP_OUT_DTHETA, s))) return rc;
+    if (dnoise && (rc = finish<T>((const T*)p->S, (const T*)p->alpha, p->N, (int)p->n, (T*)dnoise, s))) return rc;
+    if (dr) copy_n_kernel<T><<<(unsigned)((p->n + 255) / 256), 256, 0, s>>>((const T*)p->alpha, p->n, (T*)dr);
+  }
+  assemble_kernel<T><<<1, 64, 0, s>>>((const T*)p->scal, p->info, (long)p->n, p->ntheta, !with_grad, (T*)out);
+  p->have_factor = 1;
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int cross(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* Ks, hipStream_t s) {
+  const long M = round_up(m, DGP_TILE_HOST);
+  int rc = pack_x<T>((const T*)Xs, (int)m, p->d, M, (T*)work, s);
+  if (rc) return rc;
+  return gram_cross<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, (const T*)work, M, (int)m, theta, (T*)Ks, s);
+}
+
+template <typename T>
+static int predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* mean, void* var,
+                   hipStream_t s) {
+  const long M = round_up(m, DGP_TILE_HOST);
+  const size_t e = sizeof(T);
+  char* w = (char*)work;
+  T* Xst = (T*)w; w += align_up(e * M * p->d);
+  T* Ks = (T*)w; w += align_up(e * (size_t)p->N * M);
+  T* V = (T*)w; w += align_up(e * (size_t)p->N * M);
+  T* kss = (T*)w; w += align_up(e * M);
+  T* mpad = (T*)w; w += align_up(e * M);
+  T* vpad = (T*)w;
+  int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s);
+  if (rc) return rc;
+  if ((rc = gram_diag<T>(p->model, p->d, Xst, M, (int)m, theta, kss, s))) return rc;
+  if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, mpad, vpad, s))) return rc;
+  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean);
+  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(vpad, m, (T*)var);
+  return (int)hipGetLastError();
+}
+
+#define DGP_BY_DTYPE(p, CALL64, CALL32) ((p)->dtype == DGP_F64 ? (CALL64) : (CALL32))
+#define DGP_CHECK_PLAN(p)                                                        \
+  if (!(p)) return fail(DGP_E_ARG, "null plan");                                 \
+  if (!(p)->ws) return fail(DGP_E_WORKSPACE, "plan has no workspace: call dgp_plan_set_workspace")
+static int wrap(int rc, const char* where) {
+  if (rc > 0) return hipfail((hipError_t)rc, where);
+  if (rc < 0) return fail(rc, where);
+  return 0;
+}
+
+extern "C" {
+
+int dgp_set_inputs(dgp_plan* p, const void* X, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!X) return fail(DGP_E_ARG, "dgp_set_inputs: null X");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = DGP_BY_DTYPE(p, pack_x<double>((const double*)X, (int)p->n, p->d, p->N, (double*)p->Xt, s),
+                        pack_x<float>((const float*)X, (int)p->n, p->d, p->N, (float*)p->Xt, s));
+  p->have_inputs = 1;
+  p->have_factor = 0;
+  return wrap(rc, "dgp_set_inputs");
+}
+
+int dgp_fit_step(dgp_plan* p, const double* theta, const void* r, const void* noise, void* out, void* dr,
+                 void* dnoise, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!theta || !r || !noise || !out) return fail(DGP_E_ARG, "dgp_fit_step: null argument");
+  if (!p->have_inputs) return fail(DGP_E_STATE, "dgp_fit_step: call dgp_set_inputs first");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = DGP_BY_DTYPE(p, fit_step<double>(p, theta, r, noise, out, dr, dnoise, 1, s),
+                        fit_step<float>(p, theta, r, noise, out, dr, dnoise, 1, s));
+  return wrap(rc, "dgp_fit_step");
+}
+
+int dgp_factorize(dgp_plan* p, const double* theta, const void* r, const void* noise, void* out, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!theta || !r || !noise || !out) return fail(DGP_E_ARG, "dgp_factorize: null argument");
+  if (!p->have_inputs) return fail(DGP_E_STATE, "dgp_factorize: call dgp_set_inputs first");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = DGP_BY_DTYPE(p, fit_step<double>(p, theta, r, noise, out, nullptr, nullptr, 0, s),
+                        fit_step<float>(p, theta, r, noise, out, nullptr, nullptr, 0, s));
+  return wrap(rc, "dgp_factorize");
+}
+
+size_t dgp_predict_workspace_bytes(const dgp_plan* p, int64_t m) {
+  if (!p || m <= 0) return 0;
+  const size_t M = (size_t)round_up(m, DGP_TILE_HOST), e = p->elem;
+  return align_up(e * M * p->d) + 2 * align_up(e * (size_t)p->N * M) + 3 * align_up(e * M);
+}
+
+int dgp_predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
+                void* mean, void* var, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!theta || !Xs || !work || !mean || !var || m <= 0) return fail(DGP_E_ARG, "dgp_predict: null argument");
+  if (!p->have_factor) return fail(DGP_E_STATE, "dgp_predict: no factorisation in the plan (call dgp_factorize)");
+  if (work_bytes < dgp_predict_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_predict: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = DGP_BY_DTYPE(p, predict<double>(p, theta, Xs, m, work, mean, var, s),
+                        predict<float>(p, theta, Xs, m, work, mean, var, s));
+  return wrap(rc, "dgp_predict");
+}
+
+int dgp_stage_gram(dgp_plan* p, const double* theta, const void* noise, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!theta || !noise) return fail(DGP_E_ARG, "dgp_stage_gram: null argument");
+  if (!p->have_inputs) return fail(DGP_E_STATE, "dgp_stage_gram: call dgp_set_inputs first");
+  hipStream_t s = (hipStream_t)stream;
+  return wrap(DGP_BY_DTYPE(p, run_gram<double>(p, theta, noise, s), run_gram<float>(p, theta, noise, s)), "dgp_stage_gram");
+}
+int dgp_stage_potrf(dgp_plan* p, void* stream) {
+  DGP_CHECK_PLAN(p);
+  hipStream_t s = (hipStream_t)stream;
+  return wrap(DGP_BY_DTYPE(p, run_potrf<double>(p, s), run_potrf<float>(p, s)), "dgp_stage_potrf");
+}
+int dgp_stage_trtri(dgp_plan* p, void* stream) {
+  DGP_CHECK_PLAN(p);
+  hipStream_t s = (hipStream_t)stream;
+  return wrap(DGP_BY_DTYPE(p, run_trtri<double>(p, s), run_trtri<float>(p, s)), "dgp_stage_trtri");
+}
+int dgp_stage_lauum(dgp_plan* p, void* stream) {
+  DGP_CHECK_PLAN(p);
+  hipStream_t s = (hipStream_t)stream;
+  return wrap(DGP_BY_DTYPE(p, run_lauum<double>(p, s), run_lauum<float>(p, s)), "dgp_stage_lauum");
+}
+int dgp_stage_solve(dgp_plan* p, const void* r, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!r) return fail(DGP_E_ARG, "dgp_stage_solve: null r");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = DGP_BY_DTYPE(p, run_solve<double>(p, r, s), run_solve<float>(p, r, s));
+  if (!rc) p->have_factor = 1;
+  return wrap(rc, "dgp_stage_solve");
+}
+int dgp_stage_grad(dgp_plan* p, const double* theta, void* dtheta, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!theta || !dtheta) return fail(DGP_E_ARG, "dgp_stage_grad: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  return wrap(DGP_BY_DTYPE(p, run_grad<double>(p, theta, dtheta, s), run_grad<float>(p, theta, dtheta, s)), "dgp_stage_grad");
+}
+int dgp_cross_gram(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* Ks, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!theta || !Xs || !work || !Ks || m <= 0) return fail(DGP_E_ARG, "dgp_cross_gram: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  return wrap(DGP_BY_DTYPE(p, cross<double>(p, theta, Xs, m, work, Ks, s), cross<float>(p, theta, Xs, m, work, Ks, s)),
+              "dgp_cross_gram");
+}
+
+}  // extern "C"

@@ -1,0 +1,432 @@
+// dgp_chol.hip -- blocked right-looking Cholesky of K^ = K + Sigma, the explicit inverse needed by the
+// gradient trace terms, and the triangular solves of the marginal likelihood.  Hand-written for
+// gfx950; this replaces what the reference gets from gpytorch/linear_operator/LAPACK underneath
+// ExactMarginalLogLikelihood (src/discontinuum/engines/gpytorch.py:318, 353, 384).
+//
+//   potrf   for each 128-wide block column k:
+//             potrf_diag   one workgroup: L_kk and L_kk^-1 by an in-register Gauss-Jordan sweep
+//             trsm         A[i,k] <- A[i,k] L_kk^-T  as an MFMA GEMM against L_kk^-1
+//             syrk         A[i,j] -= A[i,k] A[j,k]^T (MFMA), lower tiles only
+//           with a one-panel lookahead on a second HIP stream (panel k+1 overlaps update k).
+//   trtri   T = L^-1 by log2(N/128) levels of batched MFMA GEMMs  T21 = -T22 (L21 T11)
+//   lauum   S = T^T T = K^^-1, one launch, triangular k-range per tile
+//   solve   z = T r, quad = z^T z, alpha = T^T z (bandwidth-bound, deterministic two-stage sums)
+// Flops per fit: N^3/3 (potrf) + N^3/3 (trtri) + N^3/3 (lauum) -- MFMA roofline.
+#include "dgp_gemm.h"
+#include "dgp_internal.h"
+
+namespace dgp {
+
+static constexpr int NB = DGP_TILE;
+
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);  // v_rsq_f64 (~26 good bits) + 2 Newton steps
+  const double h = 0.5 * d;
+  double e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  return y;
+}
+__device__ __forceinline__ float rsqrt_nr(float d) {
+  float y = __builtin_amdgcn_rsqf(d);
+  const float h = 0.5f * d;
+  float e = fmaf(-h * y, y, 0.5f);
+  y = fmaf(y, e, y);
+  return y;
+}
+
+// ------------------------------------------------------------------------------------------
+// Diagonal block: 256 threads own the 128x128 block cyclically (thread (ti,tj) holds cells
+// (ti+16a, tj+16b)).  Step k of the sweep eliminates pivot k from the Schur complement (cells right of
+// column k) AND from the inverse being built in the cells left of it, so after 128 steps the lower
+// cells hold L_kk^-1.  One barrier per step; the pivot row/column travel through a double-buffered
+// 128-entry LDS vector.  L_kk columns / L_kk^-1 rows are streamed out as they become final.
+template <typename T>
+__global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long ld, long k0, T* __restrict__ Tinv,
+                                                         T* __restrict__ logdet, int* __restrict__ info) {
+  __shared__ T vbuf[2][NB];
+  __shared__ T dvals[NB];
+  const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
+  T* Ablk = A + k0 * ld + k0;
+  T* Xblk = Tinv + k0 * ld + k0;
+  T reg[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) reg[a][b] = (b <= a) ? Ablk[(long)(ti + 16 * a) * ld + tj + 16 * b] : T(0);
+  if (tj == 0) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) vbuf[0][ti + 16 * a] = reg[a][0];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll 1
+    for (int kt = 0; kt < 16; ++kt) {
+      const int k = kb * 16 + kt;
+      const T* v = vbuf[k & 1];
+      T* vn = vbuf[(k + 1) & 1];
+      const T d = v[k];
+      const T s = rsqrt_nr(d);
+      if (t == 0) {
+        dvals[k] = d;
+        if (!(d > T(0))) atomicCAS(info, 0, (int)(k0 + k + 1));
+      }
+      if (t < NB) {  // row k of L_kk^-1 (zeros right of the diagonal)
+        Xblk[(long)k * ld + t] = t < k ? v[t] * s : (t == k ? s : T(0));
+      } else {  // column k of L_kk, and zeros above the diagonal
+        const int i = t - NB;
+        if (i >= k) Ablk[(long)i * ld + k] = (i == k) ? d * s : v[i] * s;
+        if (i > k) Ablk[(long)k * ld + i] = T(0);
+      }
+      // li = 0 on rows that are already final turns the update into unconditional FMAs
+      T li[8], vj[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const bool rowact = (a > kb) || (a == kb && ti > kt);
+        li[a] = rowact ? v[ti + 16 * a] * s : T(0);
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int j = tj + 16 * b;
+        vj[b] = (j == k) ? s : v[j] * s;
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        if (a < kb) continue;  // rows above the pivot block are final
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          if (b > a) continue;
+          T cur = reg[a][b];
+          if (b == kb) cur = (tj == kt) ? T(0) : cur;  // cell (i,k): Schur value consumed, inverse starts at 0
+          reg[a][b] = fma(-li[a], vj[b], cur);
+        }
+      }
+      // publish pivot column k+1 (rows >= k+1) and pivot row k+1 (columns <= k) for the next step
+      if (kt < 15) {
+        const int k1 = k + 1, kt1 = kt + 1;
+        if (tj == kt1) {
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+            if (a >= kb && ti + 16 * a >= k1) vn[ti + 16 * a] = reg[a][kb];
+        }
+        if (ti == kt1) {
+#pragma unroll
+          for (int b = 0; b < 8; ++b)
+            if (b <= kb && tj + 16 * b < k1) vn[tj + 16 * b] = reg[kb][b];
+        }
+      } else if (kb < 7) {
+        if (tj == 0) {
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+            if (a >= kb + 1) vn[ti + 16 * a] = reg[a][(kb + 1) & 7];
+        }
+        if (ti == 0) {
+#pragma unroll
+          for (int b = 0; b < 8; ++b)
+            if (b <= kb) vn[tj + 16 * b] = reg[(kb + 1) & 7][b];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // log|L_kk|^2 = sum log(pivots); fixed-order tree so the result is reproducible
+  __shared__ T red[NB];
+  if (t < NB) red[t] = log(dvals[t]);
+  __syncthreads();
+  for (int sft = 64; sft > 0; sft >>= 1) {
+    if (t < sft) red[t] += red[t + sft];
+    __syncthreads();
+  }
+  if (t == 0) logdet[0] += red[0];  // diag kernels of one factorisation run in stream order
+}
+
+// ------------------------------------------------------------------------------------------
+// A[i,k] <- A[i,k] * L_kk^-T  (L_kk^-1 lives in the diagonal block of Tinv)
+template <typename T>
+__global__ __launch_bounds__(256) void trsm_kernel(T* __restrict__ A, const T* __restrict__ Tinv, long ld, int k) {
+  using G = TileGemm<T, true, true>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  const long bi = k + 1 + blockIdx.x;
+  typename G::acc_t acc[G::MI][G::NI];
+  G::zero(acc);
+  T* Ablk = A + bi * NB * ld + (long)k * NB;
+  G::run(Ablk, ld, Tinv + (long)k * NB * ld + (long)k * NB, ld, NB / 16, smem, acc);
+  G::foreach (acc, [&](int r, int c, T& v) { Ablk[(long)r * ld + c] = v; });
+}
+
+// A[i,j] -= A[i,k] A[j,k]^T for the lower tiles with block column >= jbeg.
+// colmode: only block column jbeg (the lookahead column).
+template <typename T>
+__global__ __launch_bounds__(256) void syrk_kernel(T* __restrict__ A, long ld, int k, int jbeg, int colmode) {
+  using G = TileGemm<T, true, true>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  int bi, bj;
+  if (colmode) {
+    bi = jbeg + blockIdx.x;
+    bj = jbeg;
+  } else {
+    tri_decode(blockIdx.x, bi, bj);
+    bi += jbeg;
+    bj += jbeg;
+  }
+  typename G::acc_t acc[G::MI][G::NI];
+  G::zero(acc);
+  G::run(A + (long)bi * NB * ld + (long)k * NB, ld, A + (long)bj * NB * ld + (long)k * NB, ld, NB / 16, smem, acc);
+  T* C = A + (long)bi * NB * ld + (long)bj * NB;
+  G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] -= v; });
+}
+
+template <typename T>
+__global__ void zero1_kernel(T* p, int* info) {
+  p[0] = T(0);
+  info[0] = 0;
+}
+
+template <typename T>
+int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev) {
+  const int nbk = (int)(N / NB);
+  zero1_kernel<T><<<1, 1, 0, s>>>(logdet, info);
+  auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
+  if (!lookahead || nbk < 3 || s2 == nullptr || ev == nullptr) {
+    for (int k = 0; k < nbk; ++k) {
+      potrf_diag_kernel<T><<<1, 256, 0, s>>>(A, N, (long)k * NB, Tinv, logdet, info);
+      if (k + 1 < nbk) {
+        trsm_kernel<T><<<nbk - k - 1, 256, 0, s>>>(A, Tinv, N, k);
+        syrk_kernel<T><<<tri(nbk - k - 1), 256, 0, s>>>(A, N, k, k + 1, 0);
+      }
+    }
+    return (int)hipGetLastError();
+  }
+  // one-panel lookahead: stream s carries the panel chain, s2 the bulk trailing updates.
+  hipEvent_t* P = ev;        // P[k]: panel k (diag + trsm) ready
+  hipEvent_t* U = ev + nbk;  // U[k]: bulk update with panel k done
+  potrf_diag_kernel<T><<<1, 256, 0, s>>>(A, N, 0, Tinv, logdet, info);
+  trsm_kernel<T><<<nbk - 1, 256, 0, s>>>(A, Tinv, N, 0);
+  hipEventRecord(P[0], s);
+  int last_u = -1;
+  for (int k = 0; k + 1 < nbk; ++k) {
+    if (k + 2 < nbk) {
+      hipStreamWaitEvent(s2, P[k], 0);
+      syrk_kernel<T><<<tri(nbk - k - 2), 256, 0, s2>>>(A, N, k, k + 2, 0);
+      hipEventRecord(U[k], s2);
+      last_u = k;
+    }
+    if (k >= 1) hipStreamWaitEvent(s, U[k - 1], 0);
+    syrk_kernel<T><<<nbk - k - 1, 256, 0, s>>>(A, N, k, k + 1, 1);
+    potrf_diag_kernel<T><<<1, 256, 0, s>>>(A, N, (long)(k + 1) * NB, Tinv, logdet, info);
+    if (k + 2 < nbk) {
+      trsm_kernel<T><<<nbk - k - 2, 256, 0, s>>>(A, Tinv, N, k + 1);
+      hipEventRecord(P[k + 1], s);
+    }
+  }
+  if (last_u >= 0) hipStreamWaitEvent(s, U[last_u], 0);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// trtri level of half-size m blocks: group g covers block rows/cols [lo, hi), split at mid.
+//   W[i,j] = sum_{c=j}^{mid-1} L[i,c] T[c,j]      (i in [mid,hi), j in [lo,mid))
+//   T[i,j] = - sum_{c=mid}^{i} T[i,c] W[c,j]
+template <typename T, int STEP>
+__global__ __launch_bounds__(256) void trtri_level_kernel(const T* __restrict__ L, T* __restrict__ Tm,
+                                                          T* __restrict__ W, long ld, int m, int nbk) {
+  using G = TileGemm<T, true, false>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  const int lo = 2 * m * blockIdx.y, mid = lo + m, hi = min(lo + 2 * m, nbk);
+  const int i = mid + blockIdx.x / m, j = lo + blockIdx.x % m;
+  if (i >= hi) return;
+  typename G::acc_t acc[G::MI][G::NI];
+  G::zero(acc);
+  if (STEP == 0) {
+    G::run(L + (long)i * NB * ld + (long)j * NB, ld, Tm + (long)j * NB * ld + (long)j * NB, ld, (mid - j) * (NB / 16),
+           smem, acc);
+    T* out = W + (long)i * NB * ld + (long)j * NB;
+    G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
+  } else {
+    G::run(Tm + (long)i * NB * ld + (long)mid * NB, ld, W + (long)mid * NB * ld + (long)j * NB, ld,
+           (i - mid + 1) * (NB / 16), smem, acc);
+    T* out = Tm + (long)i * NB * ld + (long)j * NB;
+    G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = -v; });
+  }
+}
+
+template <typename T>
+int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long N, T* Tm, T* W, hipStream_t s) {
+  const int nbk = (int)(N / NB);
+  for (int m = 1; m < nbk; m *= 2) {
+    const int ngroups = (nbk + 2 * m - 1) / (2 * m);
+    dim3 grid((unsigned)(m * m), (unsigned)ngroups);
+    trtri_level_kernel<T, 0><<<grid, 256, 0, s>>>(L, Tm, W, N, m, nbk);
+    trtri_level_kernel<T, 1><<<grid, 256, 0, s>>>(L, Tm, W, N, m, nbk);
+  }
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// S[i,j] = sum_{c >= i} T[c,i]^T T[c,j]   (i >= j): K^^-1 = L^-T L^-1
+template <typename T>
+__global__ __launch_bounds__(256) void lauum_kernel(const T* __restrict__ Tm, T* __restrict__ S, long ld, int nbk) {
+  using G = TileGemm<T, false, false>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  int bi, bj;
+  tri_decode(blockIdx.x, bi, bj);  // ascending bi: the long-K tiles are dispatched first
+  typename G::acc_t acc[G::MI][G::NI];
+  G::zero(acc);
+  const T* base = Tm + (long)bi * NB * ld;
+  G::run(base + (long)bi * NB, ld, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc);
+  T* out = S + (long)bi * NB * ld + (long)bj * NB;
+  G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
+}
+
+template <typename T>
+int lauum(const T* Tm, long N, T* S, hipStream_t s) {
+  const int nbk = (int)(N / NB);
+  lauum_kernel<T><<<(unsigned)(nbk * (nbk + 1) / 2), 256, 0, s>>>(Tm, S, N, nbk);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// z_i = sum_{j <= i} T[i][j] r_j : one wave per row (coalesced along j)
+template <typename T>
+__global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ Tm, long ld, const T* __restrict__ r, int n,
+                                                     T* __restrict__ z) {
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long jend = (i / NB + 1) * NB;  // the diagonal block is zero above the diagonal
+  const T* row = Tm + i * ld;
+  T acc = T(0);
+  for (long j = lane; j < jend; j += 64) acc += row[j] * (j < n ? r[j] : T(0));
+  acc = wave_sum(acc);
+  if (lane == 0) z[i] = acc;
+}
+
+// partial[c][j] = sum_{i in chunk c, i >= blockrow(j)} T[i][j] z_i  (64 columns per workgroup)
+#define DGP_TRMV_CHUNK 512
+template <typename T>
+__global__ __launch_bounds__(256) void trmv_t_kernel(const T* __restrict__ Tm, long ld, const T* __restrict__ z,
+                                                     T* __restrict__ partial) {
+  __shared__ T red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long j = (long)blockIdx.x * 64 + tx;
+  const long r0 = (long)blockIdx.y * DGP_TRMV_CHUNK, r1 = min(r0 + (long)DGP_TRMV_CHUNK, ld);
+  const long rstart = max(r0, ((long)blockIdx.x * 64 / NB) * NB);
+  T acc = T(0);
+  for (long i = rstart + ty; i < r1; i += 4) acc += Tm[i * ld + j] * z[i];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0) partial[(long)blockIdx.y * ld + j] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trmv_t_reduce_kernel(const T* __restrict__ partial, long N, int nchunks,
+                                                            T* __restrict__ alpha) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  T acc = T(0);
+  const int c0 = (int)((j / NB) * NB / DGP_TRMV_CHUNK);
+  for (int c = c0; c < nchunks; ++c) acc += partial[(long)c * N + j];
+  alpha[j] = acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ z, long N, T* __restrict__ out) {
+  __shared__ T red[256];
+  T acc = T(0);
+  for (long i = threadIdx.x; i < N; i += 256) acc += z[i] * z[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+long solve_partials(long N) { return (N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK * N; }
+
+template <typename T>
+int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T* quad, hipStream_t s) {
+  trmv_n_kernel<T><<<(unsigned)(N / 4), 256, 0, s>>>(Tm, N, r, n, z);
+  sumsq_kernel<T><<<1, 256, 0, s>>>(z, N, quad);
+  const int nchunks = (int)((N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK);
+  dim3 grid((unsigned)(N / 64), (unsigned)nchunks);
+  trmv_t_kernel<T><<<grid, 256, 0, s>>>(Tm, N, z, partials);
+  trmv_t_reduce_kernel<T><<<(unsigned)((N + 255) / 256), 256, 0, s>>>(partials, N, nchunks, alpha);
+  return (int)hipGetLastError();
+}
+
+// dNLL/dnoise_i = 1/2 (S_ii - alpha_i^2)
+template <typename T>
+__global__ __launch_bounds__(256) void dnoise_kernel(const T* __restrict__ S, const T* __restrict__ alpha, long N,
+                                                     int n, T* __restrict__ dnoise) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dnoise[i] = T(0.5) * (S[i * N + i] - alpha[i] * alpha[i]);
+}
+
+template <typename T>
+int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s) {
+  dnoise_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(S, alpha, N, n, dnoise);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// prediction: V = T Ks (N x M, Ks = K(X, X*) padded to M % 128 == 0), var_j = kss_j - sum_i V_ij^2,
+// mean_j = sum_i Ks_ij alpha_i      (src/discontinuum/engines/gpytorch.py:621-624)
+template <typename T>
+__global__ __launch_bounds__(256) void predict_v_kernel(const T* __restrict__ Tm, long N, const T* __restrict__ Ks,
+                                                        long M, T* __restrict__ V) {
+  using G = TileGemm<T, true, false>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  typename G::acc_t acc[G::MI][G::NI];
+  G::zero(acc);
+  G::run(Tm + (long)bi * NB * N, N, Ks + (long)bj * NB, M, (bi + 1) * (NB / 16), smem, acc);
+  T* out = V + (long)bi * NB * M + (long)bj * NB;
+  G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * M + c] = v; });
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void predict_reduce_kernel(const T* __restrict__ V, const T* __restrict__ Ks, long N,
+                                                             long M, const T* __restrict__ alpha,
+                                                             const T* __restrict__ kss, T* __restrict__ mean,
+                                                             T* __restrict__ var) {
+  __shared__ T r1[4][64], r2[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long j = (long)blockIdx.x * 64 + tx;
+  T s1 = T(0), s2 = T(0);
+  for (long i = ty; i < N; i += 4) {
+    const T v = V[i * M + j];
+    s2 += v * v;
+    s1 += Ks[i * M + j] * alpha[i];
+  }
+  r1[ty][tx] = s1;
+  r2[ty][tx] = s2;
+  __syncthreads();
+  if (ty == 0) {
+    mean[j] = r1[0][tx] + r1[1][tx] + r1[2][tx] + r1[3][tx];
+    var[j] = kss[j] - (r2[0][tx] + r2[1][tx] + r2[2][tx] + r2[3][tx]);
+  }
+}
+
+template <typename T>
+int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* mean, T* var,
+                hipStream_t s) {
+  dim3 grid((unsigned)(M / NB), (unsigned)(N / NB));
+  predict_v_kernel<T><<<grid, 256, 0, s>>>(Tm, N, Ks, M, V);
+  predict_reduce_kernel<T><<<(unsigned)(M / 64), 256, 0, s>>>(V, Ks, N, M, alpha, kss, mean, var);
+  return (int)hipGetLastError();
+}
+
+#define DGP_INST(T)                                                                                              \
+  template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*);                     \
+  template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t);                                          \
+  template int lauum<T>(const T*, long, T*, hipStream_t);                                                        \
+  template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t);                             \
+  template int finish<T>(const T*, const T*, long, int, T*, hipStream_t);                                        \
+  template int predict_var<T>(const T*, long, const T*, long, T*, const T*, const T*, T*, T*, hipStream_t);
+DGP_INST(double)
+DGP_INST(float)
+
+}  // namespace dgp

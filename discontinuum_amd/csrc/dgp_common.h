@@ -1,0 +1,76 @@
+// dgp_common.h -- shared device/host helpers for the MI355X (gfx950) exact-GP engine.
+//
+// Conventions used by every kernel in this directory:
+//   * matrices are row-major N x N with leading dimension ld == N, N = round_up(n, 128);
+//     only the lower triangle (i >= j) is meaningful.  The pad region (i or j >= n) holds the
+//     identity, so chol(blockdiag(K, I)) = blockdiag(L, I): no kernel needs a bounds check and
+//     log|K|, K^-1 r are unaffected.
+//   * a wavefront is 64 lanes; MFMA is v_mfma_{f64,f32}_16x16x4 (one A and one B element per lane).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DGP_TILE 128  // block size of every blocked algorithm == padding quantum of N
+
+typedef double dgp_d4 __attribute__((ext_vector_type(4)));
+typedef float dgp_f4 __attribute__((ext_vector_type(4)));
+typedef double dgp_d2 __attribute__((ext_vector_type(2)));
+
+namespace dgp {
+
+template <typename T>
+struct Mfma;
+
+// v_mfma_f64_16x16x4_f64: lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
+// C/D: col = l&15, row = (l>>4) + 4*reg   (cdna_hip_programming.md section 3: f64 does NOT use
+// the f32 row map).
+template <>
+struct Mfma<double> {
+  using acc_t = dgp_d4;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+
+// v_mfma_f32_16x16x4_f32: same A/B maps; C/D: col = l&15, row = (l>>4)*4 + reg.
+template <>
+struct Mfma<float> {
+  using acc_t = dgp_f4;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+// 16-byte global load/store of 16/sizeof(T) consecutive elements
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<double> {
+  typedef dgp_d2 type;
+  static constexpr int N = 2;
+};
+template <>
+struct Vec16<float> {
+  typedef dgp_f4 type;
+  static constexpr int N = 4;
+};
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// map a linear index onto the lower triangle (bi >= bj) of an nb x nb block grid, row by row.
+__device__ __forceinline__ void tri_decode(int idx, int& bi, int& bj) {
+  int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+  while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+  while (i * (i + 1) / 2 > idx) --i;
+  bi = i;
+  bj = idx - i * (i + 1) / 2;
+}
+
+}  // namespace dgp

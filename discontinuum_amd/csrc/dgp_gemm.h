@@ -1,0 +1,137 @@
+// dgp_gemm.h -- LDS-tiled MFMA tile-GEMM core shared by the Cholesky / inverse / predict kernels.
+//
+// One workgroup (256 threads = 4 waves, arranged 2 x 2) accumulates a BM x BN output tile
+//     acc[i][j] += sum_k  opA(i, k) * opB(j, k)
+// over `ktiles` k-tiles of depth 16.  Each operand is addressed through a base pointer to the
+// tile's (row 0, k 0) element and is either
+//     KC  ("k-contiguous"):  op(i, k) = p[i * ld + k]     (a row-major panel, rows = i)
+//     IC  ("i-contiguous"):  op(i, k) = p[k * ld + i]     (a row-major matrix read transposed)
+// so NT / NN / TN products are the same routine.  Roofline: MFMA (fp64 16x16x4 is 64 cycles per
+// 2048 flop per SIMD); the LDS image is laid out so every ds_read_b64 fragment read is
+// bank-conflict free:  KC -> [row][17] (odd stride), IC -> [k][rows+16] (stride = 128 B mod 256 B).
+#pragma once
+#include "dgp_common.h"
+
+namespace dgp {
+
+template <typename T, bool KC, int ROWS>
+struct OperandTile {
+  static constexpr int BK = 16;
+  static constexpr int EPT = ROWS * BK / 256;  // elements staged per thread per k-tile (8 or 4)
+  static constexpr int STRIDE = KC ? (BK + 1) : (ROWS + 16);
+  static constexpr int ELEMS = KC ? ROWS * (BK + 1) : BK * (ROWS + 16);
+  static constexpr int VN = Vec16<T>::N;
+  static constexpr int NV = EPT / VN;
+  using vec_t = typename Vec16<T>::type;
+  static_assert(EPT % VN == 0, "staging vector width");
+
+  static __device__ __forceinline__ void coords(int t, int& r, int& c) {
+    if (KC) {
+      r = t / (BK / EPT);            // tile row
+      c = (t % (BK / EPT)) * EPT;    // k offset
+    } else {
+      r = t / (ROWS / EPT);          // k
+      c = (t % (ROWS / EPT)) * EPT;  // tile-row offset
+    }
+  }
+  static __device__ __forceinline__ void load(const T* __restrict__ p, long ld, T (&reg)[EPT], int t) {
+    int r, c;
+    coords(t, r, c);
+    const vec_t* src = reinterpret_cast<const vec_t*>(p + (long)r * ld + c);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      vec_t x = src[v];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) reg[v * VN + e] = x[e];
+    }
+  }
+  static __device__ __forceinline__ void store(T* __restrict__ s, const T (&reg)[EPT], int t) {
+    int r, c;
+    coords(t, r, c);
+    T* dst = s + r * STRIDE + c;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) dst[e] = reg[e];
+  }
+  // fragment element for the 16-row group starting at tile row `row0`, k-step ks (4 k's each)
+  static __device__ __forceinline__ T frag(const T* __restrict__ s, int row0, int ks, int lane) {
+    if (KC) return s[(row0 + (lane & 15)) * STRIDE + ks * 4 + (lane >> 4)];
+    return s[(ks * 4 + (lane >> 4)) * STRIDE + row0 + (lane & 15)];
+  }
+};
+
+template <typename T, bool A_KC, bool B_KC, int BM = 128, int BN = 128>
+struct TileGemm {
+  using OA = OperandTile<T, A_KC, BM>;
+  using OB = OperandTile<T, B_KC, BN>;
+  using acc_t = typename Mfma<T>::acc_t;
+  static constexpr int MI = BM / 32;  // 16-row MFMA tiles per wave in M
+  static constexpr int NI = BN / 32;
+  static constexpr int SMEM_ELEMS = OA::ELEMS + OB::ELEMS;
+
+  static __device__ __forceinline__ void zero(acc_t (&acc)[MI][NI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = T(0);
+  }
+
+  static __device__ __forceinline__ void run(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb,
+                                             int ktiles, T* __restrict__ smem, acc_t (&acc)[MI][NI]) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (BN / 2);
+    T* sA = smem;
+    T* sB = smem + OA::ELEMS;
+    const long stepA = A_KC ? 16 : 16 * lda;
+    const long stepB = B_KC ? 16 : 16 * ldb;
+    T ra[OA::EPT], rb[OB::EPT];
+    if (ktiles > 0) {
+      OA::load(A, lda, ra, t);
+      OB::load(B, ldb, rb, t);
+    }
+    for (int kt = 0; kt < ktiles; ++kt) {
+      __syncthreads();  // everyone is done reading the previous k-tile's LDS image
+      OA::store(sA, ra, t);
+      OB::store(sB, rb, t);
+      __syncthreads();
+      if (kt + 1 < ktiles) {  // next k-tile's global loads fly under this tile's MFMAs
+        A += stepA;
+        B += stepB;
+        OA::load(A, lda, ra, t);
+        OB::load(B, ldb, rb, t);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        T fa[MI], fb[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[mi] = OA::frag(sA, wm + mi * 16, ks, lane);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fb[ni] = OB::frag(sB, wn + ni * 16, ks, lane);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::mma(fa[mi], fb[ni], acc[mi][ni]);
+      }
+    }
+  }
+
+  // visit every accumulator element this lane owns: f(tile_row, tile_col, value&)
+  template <typename F>
+  static __device__ __forceinline__ void foreach (acc_t (&acc)[MI][NI], F f) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (BN / 2);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T v = acc[mi][ni][r];
+          f(wm + mi * 16 + Mfma<T>::crow(lane, r), wn + ni * 16 + (lane & 15), v);
+          acc[mi][ni][r] = v;
+        }
+  }
+};
+
+}  // namespace dgp

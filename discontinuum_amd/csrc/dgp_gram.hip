@@ -1,0 +1,312 @@
+// dgp_gram.hip -- fused kernel-Gram assembly and its hyperparameter-gradient contraction.
+//
+//   gram_sym    K^ = K(X, X; theta) + diag(noise), lower 64x64 tiles of the padded N x N matrix.
+//               Replaces gpytorch's lazy covar_module(x) + likelihood noise that the reference
+//               evaluates at src/discontinuum/engines/gpytorch.py:350-353.
+//               Bytes per launch: N(N+64)/2 * sizeof(T) written (+ d*N read) -- HBM-write roofline.
+//   gram_cross  K(X, X*) rectangular (prediction, engines/gpytorch.py:621-624).
+//   gram_grad   dNLL/dtheta_p = 1/2 sum_ij (S - alpha alpha^T)_ij dK_ij/dtheta_p for all p at once:
+//               streams S = K^^-1 once (N(N+64)/2 * sizeof(T) read), recomputes every sub-kernel in
+//               registers, wave-shuffle + LDS block reduction, deterministic two-stage sum.
+// Coordinates are SoA (d x N) so that the strip loads are coalesced; strips are staged in LDS.
+#include "dgp_internal.h"
+#include "dgp_models.h"
+
+namespace dgp {
+
+int model_ntheta(int model, int d) {
+  if (model == DGP_MODEL_LOADEST) return (d >= 2 && d <= 6) ? 2 * d + 5 : -1;
+  if (model == DGP_MODEL_RATING) return d == 2 ? 16 : -1;
+  return -1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_x_kernel(const T* __restrict__ X, int n, int d, long N, T* __restrict__ Xt) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  for (int c = 0; c < d; ++c) Xt[(long)c * N + i] = i < n ? X[i * d + c] : T(0);
+}
+
+template <typename T, typename M>
+__device__ __forceinline__ void stage_strip(const T* __restrict__ Xt, long N, long base, const typename M::Pre& pre,
+                                            T (*sf)[64], int lane) {
+  T x[M::NX], f[M::NF];
+#pragma unroll
+  for (int c = 0; c < M::NX; ++c) x[c] = Xt[(long)c * N + base + lane];
+  M::features(x, pre, f);
+#pragma unroll
+  for (int c = 0; c < M::NF; ++c) sf[c][lane] = f[c];
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* dst, const T (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<double>(double* dst, const double (&v)[4]) {
+  dgp_d2 a = {v[0], v[1]}, b = {v[2], v[3]};
+  reinterpret_cast<dgp_d2*>(dst)[0] = a;
+  reinterpret_cast<dgp_d2*>(dst)[1] = b;
+}
+template <>
+__device__ __forceinline__ void store4<float>(float* dst, const float (&v)[4]) {
+  dgp_f4 a = {v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<dgp_f4*>(dst) = a;
+}
+template <typename T>
+__device__ __forceinline__ void load4(const T* src, T (&v)[4]);
+template <>
+__device__ __forceinline__ void load4<double>(const double* src, double (&v)[4]) {
+  dgp_d2 a = reinterpret_cast<const dgp_d2*>(src)[0], b = reinterpret_cast<const dgp_d2*>(src)[1];
+  v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+}
+template <>
+__device__ __forceinline__ void load4<float>(const float* src, float (&v)[4]) {
+  dgp_f4 a = *reinterpret_cast<const dgp_f4*>(src);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, typename M>
+__global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt, long N, int n, const typename M::Pre pre,
+                                                       const T* __restrict__ noise, T* __restrict__ K) {
+  __shared__ T sfi[M::NF][64], sfj[M::NF][64];
+  int bi, bj;
+  tri_decode(blockIdx.x, bi, bj);
+  const int t = threadIdx.x;
+  if (t < 64) stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
+  else if (t < 128) stage_strip<T, M>(Xt, N, (long)bj * 64, pre, sfj, t - 64);
+  __syncthreads();
+  const int ty = t >> 4, tx = t & 15;
+  T fj[4][M::NF];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fj[b][c] = sfj[c][tx * 4 + b];
+  T dummy[M::NTHETA];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const long gi = (long)bi * 64 + ty * 4 + a;
+    T fi[M::NF];
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fi[c] = sfi[c][ty * 4 + a];
+    T out[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const long gj = (long)bj * 64 + tx * 4 + b;
+      T v = M::template pair<false>(fi, fj[b], pre, T(0), dummy);
+      if (gi >= n || gj >= n) v = (gi == gj) ? T(1) : T(0);  // identity pad
+      else if (gi == gj) v += noise[gi];
+      out[b] = v;
+    }
+    store4<T>(K + gi * N + (long)bj * 64 + tx * 4, out);
+  }
+}
+
+template <typename T, typename M>
+__global__ __launch_bounds__(256) void gram_cross_kernel(const T* __restrict__ Xt, long N, int n,
+                                                         const T* __restrict__ Xst, long Mp, int m, const typename M::Pre pre,
+                                                         T* __restrict__ Ks) {
+  __shared__ T sfi[M::NF][64], sfj[M::NF][64];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t < 64) stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
+  else if (t < 128) stage_strip<T, M>(Xst, Mp, (long)bj * 64, pre, sfj, t - 64);
+  __syncthreads();
+  const int ty = t >> 4, tx = t & 15;
+  T fj[4][M::NF];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fj[b][c] = sfj[c][tx * 4 + b];
+  T dummy[M::NTHETA];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const long gi = (long)bi * 64 + ty * 4 + a;
+    T fi[M::NF];
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fi[c] = sfi[c][ty * 4 + a];
+    T out[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const long gj = (long)bj * 64 + tx * 4 + b;
+      T v = M::template pair<false>(fi, fj[b], pre, T(0), dummy);
+      if (gi >= n || gj >= m) v = T(0);
+      out[b] = v;
+    }
+    store4<T>(Ks + gi * Mp + (long)bj * 64 + tx * 4, out);
+  }
+}
+
+// prior variance k(x*, x*) of the test points (diagonal of K**)
+template <typename T, typename M>
+__global__ __launch_bounds__(256) void gram_diag_kernel(const T* __restrict__ Xst, long Mp, int m, const typename M::Pre pre,
+                                                        T* __restrict__ kss) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  T x[M::NX], f[M::NF], dummy[M::NTHETA];
+#pragma unroll
+  for (int c = 0; c < M::NX; ++c) x[c] = Xst[(long)c * Mp + j];
+  M::features(x, pre, f);
+  T v = M::template pair<false>(f, f, pre, T(0), dummy);
+  kss[j] = j < m ? v : T(0);
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, typename M>
+__global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt, long N, int n, const typename M::Pre pre,
+                                                        const T* __restrict__ S, const T* __restrict__ alpha,
+                                                        T* __restrict__ partials) {
+  __shared__ T sfi[M::NF][64], sfj[M::NF][64], sai[64], saj[64];
+  __shared__ T red[4][M::NTHETA];
+  int bi, bj;
+  tri_decode(blockIdx.x, bi, bj);
+  const int t = threadIdx.x;
+  if (t < 64) {
+    stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
+    sai[t] = alpha[(long)bi * 64 + t];
+  } else if (t < 128) {
+    stage_strip<T, M>(Xt, N, (long)bj * 64, pre, sfj, t - 64);
+    saj[t - 64] = alpha[(long)bj * 64 + t - 64];
+  }
+  __syncthreads();
+  const int ty = t >> 4, tx = t & 15;
+  T fj[4][M::NF], aj[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    aj[b] = saj[tx * 4 + b];
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fj[b][c] = sfj[c][tx * 4 + b];
+  }
+  T acc[M::NTHETA];
+#pragma unroll
+  for (int p = 0; p < M::NTHETA; ++p) acc[p] = T(0);
+  // one entry at a time: the derivative expressions are register-hungry, occupancy hides latency
+#pragma unroll 1
+  for (int a = 0; a < 4; ++a) {
+    const long gi = (long)bi * 64 + ty * 4 + a;
+    T fi[M::NF];
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fi[c] = sfi[c][ty * 4 + a];
+    const T ai = sai[ty * 4 + a];
+    T sv[4];
+    load4<T>(S + gi * N + (long)bj * 64 + tx * 4, sv);
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
+      const long gj = (long)bj * 64 + tx * 4 + b;
+      // lower triangle counted once with weight 1 (= 1/2 * 2), diagonal with 1/2, pad with 0
+      T w = sv[b] - ai * aj[b];
+      w = (gj > gi || gi >= n) ? T(0) : (gj == gi ? T(0.5) * w : w);
+      (void)M::template pair<true>(fi, fj[b], pre, w, acc);
+    }
+  }
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int p = 0; p < M::NTHETA; ++p) {
+    T v = wave_sum(acc[p]);
+    if (lane == 0) red[wv][p] = v;
+  }
+  __syncthreads();
+  if (t < M::NTHETA) partials[(long)blockIdx.x * DGP_MAX_THETA + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
+
+// deterministic second stage: one block, fixed summation order
+template <typename T>
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ partials, long nblk, int nt,
+                                                          T* __restrict__ out) {
+  __shared__ T red[256];
+  for (int p = 0; p < nt; ++p) {
+    T v = T(0);
+    for (long b = threadIdx.x; b < nblk; b += 256) v += partials[b * DGP_MAX_THETA + p];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[p] = red[0];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+#define DGP_DISPATCH_MODEL(model, d, CALL)                   \
+  switch (model) {                                           \
+    case DGP_MODEL_LOADEST:                                  \
+      switch (d) {                                           \
+        case 2: { using M = Loadest<T, 2>; CALL; } break;    \
+        case 3: { using M = Loadest<T, 3>; CALL; } break;    \
+        case 4: { using M = Loadest<T, 4>; CALL; } break;    \
+        case 5: { using M = Loadest<T, 5>; CALL; } break;    \
+        case 6: { using M = Loadest<T, 6>; CALL; } break;    \
+        default: return -2;                                  \
+      }                                                      \
+      break;                                                 \
+    case DGP_MODEL_RATING:                                   \
+      if (d != 2) return -2;                                 \
+      { using M = Rating<T>; CALL; }                         \
+      break;                                                 \
+    default: return -2;                                      \
+  }
+
+template <typename T>
+int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s) {
+  pack_x_kernel<T><<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(X, n, d, N, Xt);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s) {
+  const int nt = model_ntheta(model, d);
+  if (nt < 0) return -2;
+  const long nb = N / 64;
+  const unsigned grid = (unsigned)(nb * (nb + 1) / 2);
+  DGP_DISPATCH_MODEL(model, d, (gram_sym_kernel<T, M><<<dim3(grid), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), noise, K)));
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int gram_cross(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,
+               T* Ks, hipStream_t s) {
+  const int nt = model_ntheta(model, d);
+  if (nt < 0) return -2;
+  dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64));
+  DGP_DISPATCH_MODEL(model, d, (gram_cross_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xt, N, n, Xst, Mp, m, M::prepare(theta), Ks)));
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int gram_diag(int model, int d, const T* Xst, long Mp, int m, const double* theta, T* kss, hipStream_t s) {
+  const int nt = model_ntheta(model, d);
+  if (nt < 0) return -2;
+  dim3 grid((unsigned)((Mp + 255) / 256));
+  DGP_DISPATCH_MODEL(model, d, (gram_diag_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xst, Mp, m, M::prepare(theta), kss)));
+  return (int)hipGetLastError();
+}
+
+long gram_grad_partials(long N) {
+  const long nb = N / 64;
+  return nb * (nb + 1) / 2 * DGP_MAX_THETA;
+}
+
+template <typename T>
+int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
+              T* partials, T* dtheta, hipStream_t s) {
+  const int nt = model_ntheta(model, d);
+  if (nt < 0) return -2;
+  const long nb = N / 64;
+  const long nblk = nb * (nb + 1) / 2;
+  DGP_DISPATCH_MODEL(model, d,
+                     (gram_grad_kernel<T, M><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), S, alpha, partials)));
+  grad_reduce_kernel<T><<<dim3(1), dim3(256), 0, s>>>(partials, nblk, nt, dtheta);
+  return (int)hipGetLastError();
+}
+
+#define DGP_INST(T)                                                                                              \
+  template int pack_x<T>(const T*, int, int, long, T*, hipStream_t);                                             \
+  template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t);             \
+  template int gram_cross<T>(int, int, const T*, long, int, const T*, long, int, const double*, T*, hipStream_t); \
+  template int gram_diag<T>(int, int, const T*, long, int, const double*, T*, hipStream_t);                      \
+  template int gram_grad<T>(int, int, const T*, long, int, const double*, const T*, const T*, T*, T*, hipStream_t);
+DGP_INST(double)
+DGP_INST(float)
+
+}  // namespace dgp

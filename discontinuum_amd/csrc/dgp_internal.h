@@ -1,0 +1,44 @@
+// dgp_internal.h -- host-side launcher declarations shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DGP_TILE_HOST 128  // == DGP_TILE in dgp_common.h
+
+namespace dgp {
+
+inline long round_up(long n, long q) { return (n + q - 1) / q * q; }
+int model_ntheta(int model, int d);  // number of constrained kernel hyperparameters, -1 if unsupported
+
+// ---- dgp_gram.hip ---------------------------------------------------------------------------
+template <typename T>
+int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s);
+template <typename T>
+int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s);
+template <typename T>
+int gram_cross(int model, int d, const T* Xt, long N, int n, const T* Xst, long M, int m, const double* theta,
+               T* Ks, hipStream_t s);
+template <typename T>
+int gram_diag(int model, int d, const T* Xst, long M, int m, const double* theta, T* kss, hipStream_t s);
+template <typename T>
+int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
+              T* partials, T* dtheta, hipStream_t s);
+long gram_grad_partials(long N);  // number of T elements `partials` must hold
+
+// ---- dgp_chol.hip ---------------------------------------------------------------------------
+template <typename T>
+int potrf(T* A, long N, T* Dinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev);
+template <typename T>
+int trtri(const T* L, const T* Dinv, long N, T* Tm, T* W, hipStream_t s);
+template <typename T>
+int lauum(const T* Tm, long N, T* S, hipStream_t s);
+template <typename T>
+int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T* quad, hipStream_t s);
+template <typename T>
+int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s);
+template <typename T>
+int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* mean, T* var,
+                hipStream_t s);
+long solve_partials(long N);
+
+}  // namespace dgp

@@ -1,0 +1,207 @@
+// dgp_models.h -- per-pair evaluators of discontinuum's two composite covariance functions and
+// their derivatives w.r.t. the CONSTRAINED hyperparameters (softplus / interval chain rule and the
+// priors stay on the host, in torch).  Everything here is evaluated in registers per matrix entry.
+//
+//   Loadest<T, D>  Scale(Periodic x Matern52)[time] + Scale(RBF-ARD)[covariates] + Scale(Matern32-ARD)[all]
+//                  reference: src/loadest_gp/models/gpytorch.py:61-128
+//   Rating<T>      g g' (shift1 + shift2) + (1-g)(1-g')' bend + base + periodic, Matern factors on
+//                  (time, log(stage + 1e-6)), g = 1/(1+exp(20 (stage - b)))
+//                  reference: src/rating_gp/models/gpytorch.py:205-372, src/rating_gp/models/kernels.py:242-382
+//
+// gpytorch formulas: RBF exp(-1/2 r^2); Matern32 (1+sqrt3 r)exp(-sqrt3 r);
+// Matern52 (1+sqrt5 r+5r^2/3)exp(-sqrt5 r); Periodic exp(-2 sin^2(pi dx/p)/l).
+// Parameter order = oracle/gp_oracle.py::loadest_gram / rating_gram.
+#pragma once
+#include "dgp_common.h"
+
+#define DGP_MAX_THETA 24
+#define DGP_MODEL_LOADEST 0
+#define DGP_MODEL_RATING 1
+
+namespace dgp {
+
+__device__ __forceinline__ void sincospi_t(double x, double* s, double* c) { sincospi(x, s, c); }
+__device__ __forceinline__ void sincospi_t(float x, float* s, float* c) { sincospif(x, s, c); }
+
+template <typename T>
+struct MaternTerm {  // value = poly * exp(-q); d value / d lengthscale = dpoly * exp(-q) / l
+  T q, poly, dpoly;
+};
+template <typename T>
+__device__ __forceinline__ MaternTerm<T> matern52(T absdelta, T inv_l) {
+  MaternTerm<T> m;
+  m.q = T(2.23606797749978969641) * absdelta * inv_l;
+  m.poly = T(1) + m.q + m.q * m.q * T(1.0 / 3.0);
+  m.dpoly = (T(1) + m.q) * m.q * m.q * T(1.0 / 3.0);
+  return m;
+}
+template <typename T>
+__device__ __forceinline__ MaternTerm<T> matern32_q(T q) {
+  MaternTerm<T> m;
+  m.q = q;
+  m.poly = T(1) + q;
+  m.dpoly = q * q;
+  return m;
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int D>
+struct Loadest {
+  static constexpr int NX = D;  // raw coordinate columns (time first)
+  static constexpr int NF = D;  // per-point features
+  static constexpr int NTHETA = 2 * D + 5;
+  struct Pre {
+    T os1, inv_lp, inv_p, inv_lm, os2, os3;
+    T inv_l2[D - 1];
+    T inv_l3[D];
+  };
+  // host side, in double: kernels receive Pre by value (uniform -> SGPRs, no per-thread divides)
+  static Pre prepare(const double* th) {
+    Pre p;
+    p.os1 = (T)th[0];
+    p.inv_lp = (T)(1.0 / th[1]);
+    p.inv_p = (T)(1.0 / th[2]);
+    p.inv_lm = (T)(1.0 / th[3]);
+    p.os2 = (T)th[4];
+    for (int j = 0; j < D - 1; ++j) p.inv_l2[j] = (T)(1.0 / th[5 + j]);
+    p.os3 = (T)th[4 + D];
+    for (int j = 0; j < D; ++j) p.inv_l3[j] = (T)(1.0 / th[5 + D + j]);
+    return p;
+  }
+  static __device__ __forceinline__ void features(const T (&x)[NX], const Pre&, T (&f)[NF]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) f[j] = x[j];
+  }
+  template <bool GRAD>
+  static __device__ __forceinline__ T pair(const T (&fi)[NF], const T (&fj)[NF], const Pre& p, T w, T (&acc)[NTHETA]) {
+    const T dt = fi[0] - fj[0];
+    T s, c;
+    sincospi_t(dt * p.inv_p, &s, &c);
+    const T s2 = s * s;
+    const MaternTerm<T> m5 = matern52(fabs(dt), p.inv_lm);
+    const T e1 = exp(T(-2) * s2 * p.inv_lp - m5.q);
+    const T base1 = e1 * m5.poly;
+    T sq2 = T(0), sq3, z3[D], z2[D - 1];
+    z3[0] = dt * p.inv_l3[0];
+    sq3 = z3[0] * z3[0];
+#pragma unroll
+    for (int j = 1; j < D; ++j) {
+      const T d = fi[j] - fj[j];
+      z2[j - 1] = d * p.inv_l2[j - 1];
+      z3[j] = d * p.inv_l3[j];
+      sq2 += z2[j - 1] * z2[j - 1];
+      sq3 += z3[j] * z3[j];
+    }
+    const T base2 = exp(T(-0.5) * sq2);
+    const MaternTerm<T> m3 = matern32_q(T(1.73205080756887729353) * sqrt(sq3));
+    const T e3 = exp(-m3.q);
+    const T base3 = m3.poly * e3;
+    const T k1 = p.os1 * base1, k2 = p.os2 * base2;
+    if (GRAD) {
+      acc[0] += w * base1;
+      acc[1] += w * k1 * T(2) * s2 * p.inv_lp * p.inv_lp;
+      acc[2] += w * k1 * T(4.0 * 3.14159265358979323846) * dt * s * c * p.inv_lp * p.inv_p * p.inv_p;
+      acc[3] += w * p.os1 * e1 * m5.dpoly * p.inv_lm;
+      acc[4] += w * base2;
+#pragma unroll
+      for (int j = 0; j < D - 1; ++j) acc[5 + j] += w * k2 * z2[j] * z2[j] * p.inv_l2[j];
+      acc[4 + D] += w * base3;
+      const T g3 = w * p.os3 * e3 * T(3);
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc[5 + D + j] += g3 * z3[j] * z3[j] * p.inv_l3[j];
+    }
+    return k1 + k2 + p.os3 * base3;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct Rating {
+  static constexpr int NX = 2;  // (time, stage)
+  static constexpr int NF = 3;  // (time, log(stage + 1e-6), gate g(stage))
+  static constexpr int NTHETA = 16;
+  struct Pre {
+    T b;
+    T os_a[2], inv_ls_a[2], inv_lt_a[2];  // cov_shift #1, #2: Matern52(stage) x Matern32(time)
+    T os_u, inv_ls_u, inv_lt_u;           // cov_bend: Matern52(stage) x Matern52(time)
+    T os_b, inv_ls_b;                     // cov_base: Matern52(stage)
+    T os_p, inv_lp, inv_p, inv_lm;        // cov_periodic: Periodic(time) x Matern52(time)
+  };
+  static Pre prepare(const double* th) {
+    Pre p;
+    p.b = (T)th[0];
+    for (int a = 0; a < 2; ++a) {
+      p.os_a[a] = (T)th[1 + 3 * a];
+      p.inv_ls_a[a] = (T)(1.0 / th[2 + 3 * a]);
+      p.inv_lt_a[a] = (T)(1.0 / th[3 + 3 * a]);
+    }
+    p.os_u = (T)th[7];
+    p.inv_ls_u = (T)(1.0 / th[8]);
+    p.inv_lt_u = (T)(1.0 / th[9]);
+    p.os_b = (T)th[10];
+    p.inv_ls_b = (T)(1.0 / th[11]);
+    p.os_p = (T)th[12];
+    p.inv_lp = (T)(1.0 / th[13]);
+    p.inv_p = (T)(1.0 / th[14]);
+    p.inv_lm = (T)(1.0 / th[15]);
+    return p;
+  }
+  static __device__ __forceinline__ void features(const T (&x)[NX], const Pre& p, T (&f)[NF]) {
+    f[0] = x[0];
+    f[1] = log(x[1] + T(1e-6));                        // LogWarpKernel, kernels.py:374-382
+    f[2] = T(1) / (T(1) + exp(T(20) * (x[1] - p.b)));  // SigmoidKernel, kernels.py:311-312 (a = 20)
+  }
+  template <bool GRAD>
+  static __device__ __forceinline__ T pair(const T (&fi)[NF], const T (&fj)[NF], const Pre& p, T w, T (&acc)[NTHETA]) {
+    const T dt = fi[0] - fj[0], adt = fabs(dt), adw = fabs(fi[1] - fj[1]);
+    const T gi = fi[2], gj = fj[2], hi = T(1) - gi, hj = T(1) - gj;
+    const T gg = gi * gj, hh = hi * hj;
+    T lower = T(0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const MaternTerm<T> ms = matern52(adw, p.inv_ls_a[a]);
+      const MaternTerm<T> mt = matern32_q(T(1.73205080756887729353) * adt * p.inv_lt_a[a]);
+      const T e = exp(-ms.q - mt.q);
+      const T base = e * ms.poly * mt.poly;
+      lower += p.os_a[a] * base;
+      if (GRAD) {
+        const T wg = w * gg;
+        acc[1 + 3 * a] += wg * base;
+        acc[2 + 3 * a] += wg * p.os_a[a] * e * ms.dpoly * mt.poly * p.inv_ls_a[a];
+        acc[3 + 3 * a] += wg * p.os_a[a] * e * ms.poly * mt.dpoly * p.inv_lt_a[a];
+      }
+    }
+    const MaternTerm<T> us = matern52(adw, p.inv_ls_u), ut = matern52(adt, p.inv_lt_u);
+    const T eu = exp(-us.q - ut.q);
+    const T baseu = eu * us.poly * ut.poly;
+    const T upper = p.os_u * baseu;
+    const MaternTerm<T> bs = matern52(adw, p.inv_ls_b);
+    const T eb = exp(-bs.q);
+    const T baseb = eb * bs.poly;
+    T s, c;
+    sincospi_t(dt * p.inv_p, &s, &c);
+    const T s2 = s * s;
+    const MaternTerm<T> pm = matern52(adt, p.inv_lm);
+    const T ep = exp(T(-2) * s2 * p.inv_lp - pm.q);
+    const T basep = ep * pm.poly;
+    const T kp = p.os_p * basep;
+    if (GRAD) {
+      // d gate / d b = a g (1 - g); the inverted gate has the opposite sign
+      const T gpi = T(20) * gi * hi, gpj = T(20) * gj * hj;
+      acc[0] += w * (lower * (gpi * gj + gi * gpj) - upper * (gpi * hj + hi * gpj));
+      const T wh = w * hh;
+      acc[7] += wh * baseu;
+      acc[8] += wh * p.os_u * eu * us.dpoly * ut.poly * p.inv_ls_u;
+      acc[9] += wh * p.os_u * eu * us.poly * ut.dpoly * p.inv_lt_u;
+      acc[10] += w * baseb;
+      acc[11] += w * p.os_b * eb * bs.dpoly * p.inv_ls_b;
+      acc[12] += w * basep;
+      acc[13] += w * kp * T(2) * s2 * p.inv_lp * p.inv_lp;
+      acc[14] += w * kp * T(4.0 * 3.14159265358979323846) * dt * s * c * p.inv_lp * p.inv_p * p.inv_p;
+      acc[15] += w * p.os_p * ep * pm.dpoly * p.inv_lm;
+    }
+    return gg * lower + hh * upper + p.os_b * baseb + kp;
+  }
+};
+
+}  // namespace dgp

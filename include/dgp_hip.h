@@ -1,0 +1,119 @@
+/* dgp_hip.h -- C ABI of libdgp_hip.so, the MI355X (gfx950) exact-GP marginal-likelihood engine.
+ *
+ * The reference (thodson-usgs/discontinuum) has NO FFI for this path: its boundary is the Python
+ * class contract of `MarginalGPyTorch` (src/discontinuum/engines/gpytorch.py:36-626) and the hot-path
+ * arithmetic is delegated to gpytorch.  Each entry point below therefore cites the reference call site
+ * whose work it replaces.  Plain pointers and sizes only: device pointers are owned by the caller
+ * (e.g. torch tensors), `stream` is a hipStream_t passed as void*, host pointers are read before
+ * the call returns.  All functions are asynchronous on `stream` and return 0 on success, a negative
+ * DGP_E* code for bad arguments, or a positive hipError_t.  No exceptions cross the ABI; a
+ * non-positive-definite matrix is reported through the `info` slot of the output vector
+ * (index of the first failing pivot, 1-based; the NLL is then NaN) so that the caller's NaN/exception
+ * guard (engines/gpytorch.py:352-382) keeps working.
+ *
+ * dtype: 0 = float64, 1 = float32 (sizeof element = 8 / 4; every device array below has that type).
+ * model: 0 = loadest-gp composite kernel, d columns (time first), 2d+5 constrained hyperparameters
+ *            (src/loadest_gp/models/gpytorch.py:61-128)
+ *        1 = rating-gp composite kernel, d = 2 (time, stage), 16 constrained hyperparameters
+ *            (src/rating_gp/models/gpytorch.py:205-372, src/rating_gp/models/kernels.py:242-382)
+ *        parameter order: DESIGN.md section "Hyperparameter vectors".
+ */
+#ifndef DGP_HIP_H
+#define DGP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGP_F64 0
+#define DGP_F32 1
+#define DGP_MODEL_LOADEST 0
+#define DGP_MODEL_RATING 1
+
+#define DGP_E_ARG (-1)       /* null pointer / bad size / bad dtype */
+#define DGP_E_MODEL (-2)     /* unsupported (model, d) */
+#define DGP_E_WORKSPACE (-3) /* workspace missing or too small */
+#define DGP_E_STATE (-4)     /* call order violated (e.g. predict before factorize) */
+
+/* output vector of dgp_fit_step / dgp_factorize, in elements of the plan dtype */
+#define DGP_OUT_NLL 0    /* 1/2 r^T K^^-1 r + 1/2 log|K^| + n/2 log 2 pi */
+#define DGP_OUT_QUAD 1   /* r^T K^^-1 r */
+#define DGP_OUT_LOGDET 2 /* log|K^| */
+#define DGP_OUT_INFO 3   /* 0, or 1-based index of the first non-positive pivot */
+#define DGP_OUT_DTHETA 4 /* d NLL / d theta_p, p = 0 .. ntheta-1 */
+#define DGP_OUT_LEN 32
+
+/* buffers exposed by dgp_plan_buffer (tests and profiling) */
+#define DGP_BUF_XT 0    /* coordinates, SoA d x N */
+#define DGP_BUF_A 1     /* K^ then its Cholesky factor L (lower), N x N row-major */
+#define DGP_BUF_T 2     /* L^-1 (lower) */
+#define DGP_BUF_S 3     /* K^^-1 (lower) */
+#define DGP_BUF_Z 4     /* L^-1 r */
+#define DGP_BUF_ALPHA 5 /* K^^-1 r */
+
+typedef struct dgp_plan dgp_plan;
+
+int dgp_version(void);
+const char* dgp_last_error(void);
+/* number of constrained kernel hyperparameters of (model, d); <0 if unsupported */
+int dgp_model_ntheta(int model, int d);
+/* padded order N = round_up(n, 128) used by every N x N buffer */
+int64_t dgp_padded_n(int64_t n);
+
+/* A plan fixes (model, dtype, n, d) and owns host-side resources only (a lookahead stream and
+ * events).  Device memory is the caller's: query the size, allocate, hand it over. */
+int dgp_plan_create(int model, int dtype, int64_t n, int d, dgp_plan** out);
+int dgp_plan_destroy(dgp_plan* plan);
+size_t dgp_plan_workspace_bytes(const dgp_plan* plan);
+int dgp_plan_set_workspace(dgp_plan* plan, void* dev_ptr, size_t bytes);
+int dgp_plan_set_lookahead(dgp_plan* plan, int enabled); /* default 1 */
+int dgp_plan_buffer(const dgp_plan* plan, int which, void** dev_ptr, int64_t* ld);
+
+/* Training inputs X (n x d row-major, device) -> internal SoA copy.  Replaces the train_x tensor
+ * handed to ExactGP at engines/gpytorch.py:221-235. */
+int dgp_set_inputs(dgp_plan* plan, const void* X_dev, void* stream);
+
+/* One fit step = one evaluation of the data term of the objective and ALL its gradients, the work of
+ * `output = model(train_x); nll = -mll(output, train_y); objective.backward()` at
+ * engines/gpytorch.py:350-384 (minus the O(P) prior / constraint algebra, which stays in torch):
+ *   theta_host  ntheta constrained kernel hyperparameters (host, double)
+ *   r_dev       residual y - mean(X) (n)          noise_dev  diagonal of Sigma (n)
+ *   out_dev     DGP_OUT_LEN elements, layout DGP_OUT_*
+ *   dr_dev      d NLL / d r = alpha = K^^-1 r (n)
+ *   dnoise_dev  d NLL / d noise_i = 1/2 (K^^-1_ii - alpha_i^2) (n)
+ * Leaves L, L^-1, K^^-1, alpha in the plan buffers. */
+int dgp_fit_step(dgp_plan* plan, const double* theta_host, const void* r_dev, const void* noise_dev,
+                 void* out_dev, void* dr_dev, void* dnoise_dev, void* stream);
+
+/* Value only (no K^^-1, no gradient): Gram, Cholesky, L^-1, alpha.  out_dev as above with dtheta = 0.
+ * This is the eval-mode cache build of ExactGP (engines/gpytorch.py:618-622). */
+int dgp_factorize(dgp_plan* plan, const double* theta_host, const void* r_dev, const void* noise_dev,
+                  void* out_dev, void* stream);
+
+/* Workspace for dgp_predict on m test points. */
+size_t dgp_predict_workspace_bytes(const dgp_plan* plan, int64_t m);
+/* Posterior at Xs (m x d row-major, device) from the factorisation currently held by the plan:
+ *   mean_dev[j] = K(x*_j, X) alpha            (add the mean function on the host)
+ *   var_dev[j]  = k(x*_j, x*_j) - || L^-1 K(X, x*_j) ||^2   (latent f; add likelihood noise on the host)
+ * Replaces `self.likelihood(self.model(x))` .mean/.variance at engines/gpytorch.py:621-624. */
+int dgp_predict(dgp_plan* plan, const double* theta_host, const void* Xs_dev, int64_t m, void* work_dev,
+                size_t work_bytes, void* mean_dev, void* var_dev, void* stream);
+
+/* ---- single stages on the plan buffers, for parity tests and per-kernel profiling ---- */
+int dgp_stage_gram(dgp_plan* plan, const double* theta_host, const void* noise_dev, void* stream);
+int dgp_stage_potrf(dgp_plan* plan, void* stream);  /* A: K^ -> L ; T diag blocks <- L_kk^-1 */
+int dgp_stage_trtri(dgp_plan* plan, void* stream);  /* T <- L^-1 */
+int dgp_stage_lauum(dgp_plan* plan, void* stream);  /* S <- T^T T */
+int dgp_stage_solve(dgp_plan* plan, const void* r_dev, void* stream); /* z, alpha, quad */
+int dgp_stage_grad(dgp_plan* plan, const double* theta_host, void* dtheta_dev, void* stream);
+/* rectangular K(X, Xs) into caller memory (N x M row-major, M = dgp_padded_n(m)); Xs as in dgp_predict;
+ * work_dev holds the SoA copy of Xs (d * M elements) */
+int dgp_cross_gram(dgp_plan* plan, const double* theta_host, const void* Xs_dev, int64_t m, void* work_dev,
+                   void* Ks_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGP_HIP_H */

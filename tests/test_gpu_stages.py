@@ -1,0 +1,187 @@
+"""GPU parity of every stage of the HIP hot path against the CPU oracle (same seeded inputs).
+
+All calls go through the C ABI (libdgp_hip.so via ctypes).  Tolerances (fp64 path):
+  Gram entries abs 1e-13; Cholesky / inverse factors rel 1e-9 (Frobenius); NLL rel 1e-10;
+  hyperparameter gradients rel 1e-8 (of the gradient's max-norm); alpha / dnoise rel 1e-8;
+  posterior mean abs 1e-9, variance rel 1e-8 (+1e-12 abs).
+fp32 path: NLL rel 1e-4 * max(1, n/1024), gradients rel 1e-2, mean/var abs 1e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("loadest", 2, 200),
+    ("loadest", 3, 384),
+    ("loadest", 3, 1000),
+    ("loadest", 4, 300),
+    ("rating", 2, 200),
+    ("rating", 2, 900),
+]
+
+
+def make_case(model, d, n, seed=0, perturb=0.0):
+    g = torch.Generator().manual_seed(seed)
+    if model == "loadest":
+        X, y = orc.synth_loadest(n, d, seed)
+        m = orc.LoadestOracle(d)
+        raw = m.init_raw() + perturb * torch.randn(m.nraw, generator=g, dtype=orc.DT)
+        X, y = torch.tensor(X), torch.tensor(y)
+        noise = m.noise(raw, n)
+        r = y - m.mean(raw, X)
+    else:
+        X, y, yu = orc.synth_rating(n, seed)
+        X, y, yu = torch.tensor(X), torch.tensor(y), torch.tensor(yu)
+        m = orc.RatingOracle.from_stage(X[:, 1])
+        raw = torch.zeros(20, dtype=orc.DT)
+        raw[1], raw[2] = 1.6, 0.5
+        raw[3] = -5.0
+        raw = raw + perturb * torch.randn(20, generator=g, dtype=orc.DT)
+        m.clamp_(raw, X[:, 1].min())
+        noise = m.noise(raw, n, yu)
+        r = y - m.mean(raw, X)
+    theta = m.constrained(raw)
+    return X, r.detach(), noise.detach(), theta.detach()
+
+
+def plan_for(model, d, n, X, dtype, dev, lookahead=True):
+    from discontinuum_amd.backend import GPPlan
+
+    p = GPPlan(model, n, d, dtype=dtype, device=dev, lookahead=lookahead)
+    p.set_inputs(X.to(dev, dtype).contiguous())
+    return p
+
+
+def tril_n(t, n):
+    return torch.tril(t[:n, :n]).cpu().double()
+
+
+@pytest.mark.parametrize("model,d,n", CASES)
+def test_stages_fp64(model, d, n, gpu_device):
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=1, perturb=0.3)
+    Khat = orc.GRAMS[model](X, X, theta) + torch.diag(noise)
+    p = plan_for(model, d, n, X, torch.float64, dev)
+    # -- Gram
+    p.stage_gram(theta, noise.to(dev))
+    A = p.buffer(_lib.BUF_A)
+    assert (tril_n(A, n) - torch.tril(Khat)).abs().max() < 1e-13
+    N = p.N
+    if N > n:  # identity pad
+        pad = A[n:, :].cpu()
+        assert torch.equal(torch.tril(pad[:, n:]), torch.eye(N - n, dtype=torch.float64))
+        assert pad[:, :n].abs().max() == 0
+    # -- Cholesky
+    p.stage_potrf()
+    L_ref = torch.linalg.cholesky(Khat)
+    L = tril_n(p.buffer(_lib.BUF_A), n)
+    assert torch.linalg.norm(L - L_ref) / torch.linalg.norm(L_ref) < 1e-9
+    # -- L^-1
+    p.stage_trtri()
+    T = tril_n(p.buffer(_lib.BUF_T), n)
+    eye = torch.eye(n, dtype=torch.float64)
+    assert torch.linalg.norm(T @ L_ref - eye) / np.sqrt(n) < 1e-9
+    # -- K^-1
+    p.stage_lauum()
+    S = tril_n(p.buffer(_lib.BUF_S), n)
+    S_full = S + S.T - torch.diag(torch.diagonal(S))
+    assert torch.linalg.norm(S_full @ Khat - eye) / np.sqrt(n) < 1e-7
+    # -- solves
+    p.stage_solve(r.to(dev))
+    alpha_ref = torch.cholesky_solve(r[:, None], L_ref)[:, 0]
+    alpha = p.buffer(_lib.BUF_ALPHA)[:n].cpu()
+    assert (alpha - alpha_ref).abs().max() / alpha_ref.abs().max() < 1e-8
+    if N > n:
+        assert p.buffer(_lib.BUF_ALPHA)[n:].abs().max().item() == 0
+    # -- gradient contraction
+    g = p.stage_grad(theta).cpu()
+    _, g_ref, _, _ = orc.nll_data_and_grads(model, X, r, noise, theta)
+    assert (g - g_ref).abs().max() / g_ref.abs().max() < 1e-8
+
+
+@pytest.mark.parametrize("model,d,n", CASES)
+@pytest.mark.parametrize("lookahead", [True, False])
+def test_fit_step_fp64(model, d, n, lookahead, gpu_device):
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=2, perturb=0.2)
+    val, g_theta, g_r, g_noise = orc.nll_data_and_grads(model, X, r, noise, theta)
+    p = plan_for(model, d, n, X, torch.float64, dev, lookahead=lookahead)
+    out, dr, dnoise = p.fit_step(theta, r.to(dev), noise.to(dev))
+    out = out.cpu()
+    assert out[_lib.OUT_INFO] == 0
+    assert abs(out[_lib.OUT_NLL] - val) / abs(val) < 1e-10
+    P = theta.numel()
+    assert (out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + P] - g_theta).abs().max() / g_theta.abs().max() < 1e-8
+    assert (dr.cpu() - g_r).abs().max() / g_r.abs().max() < 1e-8
+    assert (dnoise.cpu() - g_noise).abs().max() / g_noise.abs().max() < 1e-8
+    # repeated call is bitwise reproducible (deterministic reductions)
+    out2, dr2, _ = p.fit_step(theta, r.to(dev), noise.to(dev))
+    assert torch.equal(out2.cpu(), out) and torch.equal(dr2, dr)
+
+
+@pytest.mark.parametrize("model,d,n", [("loadest", 3, 700), ("rating", 2, 500)])
+def test_fit_step_fp32(model, d, n, gpu_device):
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=3, perturb=0.1)
+    val, g_theta, g_r, g_noise = orc.nll_data_and_grads(model, X, r, noise, theta)
+    p = plan_for(model, d, n, X, torch.float32, dev)
+    out, dr, dnoise = p.fit_step(theta, r.to(dev, torch.float32), noise.to(dev, torch.float32))
+    out = out.cpu().double()
+    assert out[_lib.OUT_INFO] == 0
+    assert abs(out[_lib.OUT_NLL] - val) / abs(val) < 1e-4 * max(1.0, n / 1024)
+    P = theta.numel()
+    assert (out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + P] - g_theta).abs().max() / g_theta.abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("model,d,n,m", [("loadest", 3, 500, 333), ("rating", 2, 400, 130), ("loadest", 2, 300, 300)])
+def test_predict_fp64(model, d, n, m, gpu_device):
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=4, perturb=0.2)
+    Xs, *_ = make_case(model, d, m, seed=5)
+    mu_ref, var_ref = orc.posterior(model, X, r, noise, theta, Xs)
+    p = plan_for(model, d, n, X, torch.float64, dev)
+    p.factorize(theta, r.to(dev), noise.to(dev))
+    mu, var = p.predict(theta, Xs.to(dev), chunk=200)
+    assert (mu.cpu() - mu_ref).abs().max() < 1e-9
+    assert ((var.cpu() - var_ref).abs() / (var_ref.abs() + 1e-4)).max() < 1e-8
+    Ks = p.cross_gram(theta, Xs.to(dev)).cpu()
+    assert (Ks - orc.GRAMS[model](X, Xs, theta)).abs().max() < 1e-13
+
+
+def test_not_positive_definite_reports_info(gpu_device):
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    n, d = 300, 2
+    X, r, noise, theta = make_case("loadest", d, n, seed=6)
+    X[150] = X[149]  # duplicate point ...
+    noise = torch.full((n,), -0.5, dtype=torch.float64)  # ... and a negative "noise": K^ is indefinite
+    p = plan_for("loadest", d, n, X, torch.float64, dev)
+    out, _, _ = p.fit_step(theta, r.to(dev), noise.to(dev))
+    out = out.cpu()
+    assert out[_lib.OUT_INFO] >= 1
+    assert not torch.isfinite(out[_lib.OUT_NLL])
+
+
+def test_bad_arguments_fail_loudly(gpu_device):
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    with pytest.raises(ValueError):
+        GPPlan("rating", 100, 3, device=gpu_device)
+    p = GPPlan("loadest", 100, 2, device=gpu_device)
+    r = torch.zeros(100, dtype=torch.float64, device=gpu_device)
+    with pytest.raises(_lib.DGPError):  # no inputs yet
+        p.fit_step(torch.ones(9), r, r)
+    with pytest.raises(ValueError):
+        p.fit_step(torch.ones(5), r, r)
