@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GP fits/sec (NLL + gradient step) for the loadest-gp kernel, n=8192 d=3 fp64.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one `dgp_fit_step` through the C ABI: Gram build, blocked Cholesky, L^-1, K^^-1, NLL and
+all hyperparameter / residual / noise gradients for one site, inputs resident in HBM
+(BASELINE.json configs[1]).  With N > 1 every rank owns one independent site
+(seed = rank, weak scaling, no data-path collective); the only RCCL traffic is the gather of the
+(NLL, gradient) vectors at the end of the timed region.  Rank 0 prints ONE JSON line.
+
+`roofline`     dominant kernel of the step, timed live with HIP events recorded inside the library on the
+               stream each kernel is launched on (last timed step).  Algorithmic flops per DESIGN.md.
+`cpu_baseline` the CPU oracle (a dense torch fp64 restatement of the reference's gpytorch math -- gpytorch
+               itself is not installable here) timed on the host cores, rank 0 / N=1 only, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # MI355X dense vector/matrix peaks (MI355X_MICROARCH.md; fp64 spec)
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_loadest(n, d, seed):
+    """SURVEY.md section 8d synthetic site: sorted centred decimal years, N(0,1) covariates, standardised target."""
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(-16.0, 16.0, n))
+    cov = rng.standard_normal((n, d - 1))
+    y = 0.8 * np.sin(2 * np.pi * t) + 0.5 * cov[:, 0] + 0.1 * t / 16.0 + 0.3 * rng.standard_normal(n)
+    y = (y - y.mean()) / y.std()
+    return np.concatenate([t[:, None], cov], axis=1), y
+
+
+def syrk_flops(N, lookahead=True):
+    """Algorithmic flops of the bulk trailing-update launches of one factorisation (128x128x128 tiles)."""
+    nbk = N // 128
+    tiles = 0
+    launches = 0
+    for k in range(nbk):
+        m = nbk - k - (2 if lookahead else 1)
+        if m > 0:
+            tiles += m * (m + 1) // 2
+            launches += 1
+    return tiles * 2.0 * 128 ** 3, launches
+
+
+def cpu_baseline(n, d, dtype_name, budget_s=45.0):
+    """Time the oracle's NLL + gradient step on the host.  Probe at n=2048, then run the largest
+    n <= target whose cubic extrapolation fits the budget."""
+    from oracle import gp_oracle as orc
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one(nn):
+        X, y = synth_loadest(nn, d, 0)
+        X, y = torch.tensor(X), torch.tensor(y)
+        theta = torch.full((orc.loadest_ntheta(d),), 0.6931471805599453, dtype=torch.float64)
+        noise = torch.full((nn,), 0.01, dtype=torch.float64)
+        t0 = time.perf_counter()
+        orc.nll_data_and_grads("loadest", X, y, noise, theta)
+        return time.perf_counter() - t0
+
+    probe_n = min(2048, n)
+    one(min(512, n))  # warm the thread pool / allocator
+    t_probe = one(probe_n)
+    ns = n
+    while ns > probe_n and t_probe * (ns / probe_n) ** 3 > budget_s:
+        ns //= 2
+    t_s = t_probe if ns == probe_n else one(ns)
+    fits = 1.0 / t_s
+    scaled = fits * (ns / n) ** 3
+    sample = (f"1 NLL+grad step of oracle/gp_oracle.py (torch CPU fp64 dense, autograd) at n={ns} d={d}, "
+              f"{cores} threads, {t_s:.2f} s")
+    if ns != n:
+        sample += f"; value scaled to n={n} by (n_s/n)^3"
+    return {"value": scaled, "unit": "fits/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--d", type=int, default=3)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lookahead", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: PLW0621
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dt = torch.float64 if args.dtype == "f64" else torch.float32
+    n, d = args.n, args.d
+    X, y = synth_loadest(n, d, seed=rank)  # one independent site per rank
+    Xd = torch.tensor(X, dtype=dt, device=dev).contiguous()
+    yd = torch.tensor(y, dtype=dt, device=dev).contiguous()
+    noise = torch.full((n,), 0.01, dtype=dt, device=dev)
+    ntheta = 2 * d + 5
+    theta = [0.6931471805599453] * ntheta  # gpytorch defaults: softplus(0)
+    plan = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=not args.no_lookahead)
+    plan.set_inputs(Xd)
+    plan.set_timing(rank == 0)
+
+    out = None
+    for _ in range(args.warmup):
+        out, _, _ = plan.fit_step(theta, yd, noise)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, dr, dn = plan.fit_step(theta, yd, noise)
+    if dist is not None:  # the batch gather: (NLL, info, gradient) of every site
+        gathered = [torch.empty_like(out) for _ in range(world)]
+        dist.all_gather(gathered, out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    host = out.cpu().double()
+    assert host[_lib.OUT_INFO] == 0 and torch.isfinite(host[_lib.OUT_NLL]), "fit step failed"
+
+    if rank == 0:
+        N = plan.N
+        ms = plan.get_timing()
+        esz = 8 if args.dtype == "f64" else 4
+        peak = PEAK_TFLOPS[args.dtype]
+        f_syrk, n_syrk = syrk_flops(N, lookahead=not args.no_lookahead)
+        stages = {
+            "syrk_kernel": {"flops": f_syrk, "ms": ms[_lib.TIME_SYRK_SUM], "launches": int(ms[_lib.TIME_SYRK_N])},
+            "trtri_level_kernel": {"flops": N ** 3 / 3.0, "ms": ms[_lib.TIME_TRTRI], "launches": None},
+            "lauum_kernel": {"flops": N ** 3 / 3.0, "ms": ms[_lib.TIME_LAUUM], "launches": 1},
+        }
+        for v in stages.values():
+            v["tflops"] = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None
+        dom = max(stages, key=lambda k: stages[k]["ms"])
+        ach = stages[dom]["tflops"]
+        gram_bytes = N * (N + 64) / 2 * esz + n * d * esz
+        roofline = {
+            "bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak if ach else None, "traffic": None,
+            "launches_per_step": stages[dom]["launches"], "ms_per_step": stages[dom]["ms"],
+            "stages_tflops": {k: v["tflops"] for k, v in stages.items()},
+            "stages_ms": {"gram": ms[_lib.TIME_GRAM], "potrf_wall": ms[_lib.TIME_POTRF], "syrk_sum": ms[_lib.TIME_SYRK_SUM],
+                          "trtri": ms[_lib.TIME_TRTRI], "lauum": ms[_lib.TIME_LAUUM], "solve": ms[_lib.TIME_SOLVE],
+                          "grad": ms[_lib.TIME_GRAD]},
+            "step_flops": float(N) ** 3, "step_tflops": float(N) ** 3 * args.steps / elapsed / 1e12 * 1.0,
+            "gram_hbm": {"bound": "hbm", "achieved": gram_bytes / (ms[_lib.TIME_GRAM] * 1e-3) / 1e9 if ms[_lib.TIME_GRAM] > 0 else None,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes": gram_bytes},
+        }
+        result = {
+            "metric": "GP fits/sec (NLL+grad step) at n=8192 d=3, 1/2/4/8 MI355X",
+            "value": world * args.steps / elapsed,
+            "unit": "fits/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"synthetic loadest-gp kernel, n={n} d={d} {args.dtype} exact GP, one site per GPU",
+                       "n": n, "d": d, "sites_per_gpu": 1, "lookahead": not args.no_lookahead,
+                       "nll": float(host[_lib.OUT_NLL])},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(n, d, args.dtype)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ F64, F32 = 0, 1
 MODEL_LOADEST, MODEL_RATING = 0, 1
 OUT_NLL, OUT_QUAD, OUT_LOGDET, OUT_INFO, OUT_DTHETA, OUT_LEN = 0, 1, 2, 3, 4, 32
 BUF_XT, BUF_A, BUF_T, BUF_S, BUF_Z, BUF_ALPHA = range(6)
+TIME_GRAM, TIME_POTRF, TIME_SYRK_SUM, TIME_SYRK_N, TIME_TRTRI, TIME_LAUUM, TIME_SOLVE, TIME_GRAD, TIME_COUNT = range(9)
 
 
 class DGPLibraryError(RuntimeError):
@@ -48,6 +49,9 @@ SIGNATURES = {
     "dgp_factorize": (_i, [_vp, _dp, _vp, _vp, _vp, _vp]),
     "dgp_predict_workspace_bytes": (_sz, [_vp, _i64]),
     "dgp_predict": (_i, [_vp, _dp, _vp, _i64, _vp, _sz, _vp, _vp, _vp]),
+    "dgp_posterior_cov": (_i, [_vp, _dp, _vp, _i64, _vp, _sz, _vp, _vp, _vp]),
+    "dgp_plan_set_timing": (_i, [_vp, _i]),
+    "dgp_plan_get_timing": (_i, [_vp, _dp]),
     "dgp_stage_gram": (_i, [_vp, _dp, _vp, _vp]),
     "dgp_stage_potrf": (_i, [_vp, _vp]),
     "dgp_stage_trtri": (_i, [_vp, _vp]),

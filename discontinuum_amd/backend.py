@@ -154,6 +154,67 @@ class GPPlan:
                 )
         return mean, var
 
+    def posterior_factor(self, theta, Xs: torch.Tensor, jitter: float | None = None):
+        """(K*^T alpha, Cholesky factor of the latent posterior covariance at Xs) for ``sample()``.
+        The m x m covariance K** - V^T V comes from ``dgp_posterior_cov``; its factor from the same
+        blocked HIP potrf as the training matrix (a second plan of order m).  ``jitter`` follows
+        linear_operator's psd_safe_cholesky default for the dtype."""
+        th = _theta_array(theta, self.ntheta)
+        m = Xs.shape[0]
+        M = int(self.lib.dgp_padded_n(m))
+        if jitter is None:
+            jitter = 1e-8 if self.dtype == torch.float64 else 1e-6
+        with torch.cuda.device(self.device):
+            xs = Xs.contiguous()
+            need = int(self.lib.dgp_predict_workspace_bytes(self._h, m))
+            work = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            base = work.data_ptr() + (-work.data_ptr()) % 256
+            mean = torch.empty(m, dtype=self.dtype, device=self.device)
+            fac = GPPlan(self.model, m, self.d, dtype=self.dtype, device=self.device)
+            cov = fac.buffer(_lib.BUF_A)
+            assert cov.shape == (M, M)
+            _lib.check(
+                self.lib.dgp_posterior_cov(self._h, th, _ptr(xs), m, C.c_void_p(base), need, _ptr(mean), _ptr(cov), _stream()),
+                "dgp_posterior_cov",
+            )
+            info = -1
+            for attempt in range(4):  # psd_safe_cholesky-style escalation: jitter, 10x, 100x, 1000x
+                if attempt:
+                    _lib.check(
+                        self.lib.dgp_posterior_cov(self._h, th, _ptr(xs), m, C.c_void_p(base), need, _ptr(mean), _ptr(cov), _stream()),
+                        "dgp_posterior_cov",
+                    )
+                cov.diagonal()[:m].add_(jitter * 10 ** attempt)
+                fac.stage_potrf()
+                info = fac.potrf_info()
+                if info == 0:
+                    break
+            if info != 0:
+                raise RuntimeError(f"posterior covariance not positive definite (pivot {info})")
+            L = torch.tril(cov[:m, :m]).clone()
+        return mean, L
+
+    def potrf_info(self) -> int:
+        """info of the last factorisation (0 = ok, k = first non-positive pivot), synchronising."""
+        off = self._info_offset()
+        return int(self._ws[off:off + 4].view(torch.int32)[0].item())
+
+    def _info_offset(self):
+        # the int info slot sits right after the 16-element scalar block that follows the partials;
+        # recover it from the ALPHA buffer pointer is fragile, so the library exposes it as buffer 6
+        p, ld = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.dgp_plan_buffer(self._h, 6, C.byref(p), C.byref(ld)), "dgp_plan_buffer")
+        return p.value - self._ws.data_ptr()
+
+    def set_timing(self, enabled: bool):
+        _lib.check(self.lib.dgp_plan_set_timing(self._h, int(bool(enabled))), "dgp_plan_set_timing")
+
+    def get_timing(self):
+        """Per-stage HIP-event milliseconds of the most recent fit step (include/dgp_hip.h DGP_TIME_*)."""
+        ms = (C.c_double * _lib.TIME_COUNT)()
+        _lib.check(self.lib.dgp_plan_get_timing(self._h, ms), "dgp_plan_get_timing")
+        return list(ms)
+
     # ------------------------------------------------------------------ single stages (tests, profiling)
     def stage_gram(self, theta, noise):
         self._check_vec(noise, "noise")

@@ -32,7 +32,13 @@ struct dgp_plan {
   hipStream_t s2;
   hipEvent_t* ev;
   int nev;
+  // optional HIP-event timing of the fit-step stages
+  int timing, n_syrk, timed_valid;
+  hipEvent_t* tev;   // 2 per stage (start, stop)
+  hipEvent_t* sev;   // 2 per bulk syrk launch
+  int nsev;
 };
+enum { TS_GRAM = 0, TS_POTRF, TS_TRTRI, TS_LAUUM, TS_SOLVE, TS_GRAD, TS_COUNT };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -90,6 +96,14 @@ int dgp_plan_destroy(dgp_plan* p) {
     for (int i = 0; i < p->nev; ++i) (void)hipEventDestroy(p->ev[i]);
     delete[] p->ev;
   }
+  if (p->tev) {
+    for (int i = 0; i < 2 * TS_COUNT; ++i) (void)hipEventDestroy(p->tev[i]);
+    delete[] p->tev;
+  }
+  if (p->sev) {
+    for (int i = 0; i < p->nsev; ++i) (void)hipEventDestroy(p->sev[i]);
+    delete[] p->sev;
+  }
   if (p->s2) (void)hipStreamDestroy(p->s2);
   delete p;
   return 0;
@@ -134,6 +148,7 @@ int dgp_plan_buffer(const dgp_plan* p, int which, void** dev_ptr, int64_t* ld) {
     case DGP_BUF_S: q = p->S; break;
     case DGP_BUF_Z: q = p->z; break;
     case DGP_BUF_ALPHA: q = p->alpha; break;
+    case DGP_BUF_INFO: q = p->info; break;
     default: return fail(DGP_E_ARG, "dgp_plan_buffer: unknown buffer");
   }
   *dev_ptr = q;
@@ -146,8 +161,12 @@ int dgp_plan_buffer(const dgp_plan* p, int which, void** dev_ptr, int64_t* ld) {
 // ---------------------------------------------------------------------------------------------
 static int ensure_async(dgp_plan* p) {
   if (!p->lookahead || p->s2) return 0;
-  hipError_t e = hipStreamCreateWithFlags(&p->s2, hipStreamNonBlocking);
-  if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithFlags");
+  // the bulk trailing updates run at the LOWEST priority so that the latency-critical panel chain on
+  // the caller's stream gets the CUs first whenever both have workgroups ready
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  hipError_t e = hipStreamCreateWithPriority(&p->s2, hipStreamNonBlocking, least);
+  if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithPriority");
   p->nev = 2 * (int)(p->N / DGP_TILE_HOST);
   p->ev = new (std::nothrow) hipEvent_t[p->nev];
   if (!p->ev) return fail(DGP_E_ARG, "out of host memory");
@@ -156,6 +175,26 @@ static int ensure_async(dgp_plan* p) {
     if (e != hipSuccess) return hipfail(e, "hipEventCreateWithFlags");
   }
   return 0;
+}
+
+static int ensure_timing(dgp_plan* p) {
+  if (!p->timing || p->tev) return 0;
+  p->tev = new (std::nothrow) hipEvent_t[2 * TS_COUNT];
+  p->nsev = 2 * (int)(p->N / DGP_TILE_HOST);
+  p->sev = new (std::nothrow) hipEvent_t[p->nsev];
+  if (!p->tev || !p->sev) return fail(DGP_E_ARG, "out of host memory");
+  for (int i = 0; i < 2 * TS_COUNT; ++i) {
+    hipError_t e = hipEventCreate(&p->tev[i]);
+    if (e != hipSuccess) return hipfail(e, "hipEventCreate");
+  }
+  for (int i = 0; i < p->nsev; ++i) {
+    hipError_t e = hipEventCreate(&p->sev[i]);
+    if (e != hipSuccess) return hipfail(e, "hipEventCreate");
+  }
+  return 0;
+}
+static void tick(dgp_plan* p, int stage, int stop, hipStream_t s) {
+  if (p->timing && p->tev) (void)hipEventRecord(p->tev[2 * stage + stop], s);
 }
 
 template <typename T>
@@ -186,7 +225,9 @@ template <typename T>
 static int run_potrf(dgp_plan* p, hipStream_t s) {
   int rc = ensure_async(p);
   if (rc) return rc;
-  return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, p->lookahead, s, p->s2, p->ev);
+  if ((rc = ensure_timing(p))) return rc;
+  return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, p->lookahead, s, p->s2, p->ev,
+                  p->timing ? p->sev : nullptr, &p->n_syrk);
 }
 template <typename T>
 static int run_trtri(dgp_plan* p, hipStream_t s) {
@@ -211,13 +252,28 @@ template <typename T>
 static int fit_step(dgp_plan* p, const double* theta, const void* r, const void* noise, void* out, void* dr,
                     void* dnoise, int with_grad, hipStream_t s) {
   int rc;
+  if ((rc = ensure_timing(p))) return rc;
+  tick(p, TS_GRAM, 0, s);
   if ((rc = run_gram<T>(p, theta, noise, s))) return rc;
+  tick(p, TS_GRAM, 1, s);
+  tick(p, TS_POTRF, 0, s);
   if ((rc = run_potrf<T>(p, s))) return rc;
+  tick(p, TS_POTRF, 1, s);
+  tick(p, TS_TRTRI, 0, s);
   if ((rc = run_trtri<T>(p, s))) return rc;
+  tick(p, TS_TRTRI, 1, s);
+  tick(p, TS_SOLVE, 0, s);
   if ((rc = run_solve<T>(p, r, s))) return rc;
+  tick(p, TS_SOLVE, 1, s);
+  p->timed_valid = 0;
   if (with_grad) {
+    tick(p, TS_LAUUM, 0, s);
     if ((rc = run_lauum<T>(p, s))) return rc;
+    tick(p, TS_LAUUM, 1, s);
+    tick(p, TS_GRAD, 0, s);
     if ((rc = run_grad<T>(p, theta, (T*)out + DGP_OUT_DTHETA, s))) return rc;
+    tick(p, TS_GRAD, 1, s);
+    p->timed_valid = p->timing && p->tev;
     if (dnoise && (rc = finish<T>((const T*)p->S, (const T*)p->alpha, p->N, (int)p->n, (T*)dnoise, s))) return rc;
     if (dr) copy_n_kernel<T><<<(unsigned)((p->n + 255) / 256), 256, 0, s>>>((const T*)p->alpha, p->n, (T*)dr);
   }
@@ -253,6 +309,29 @@ static int predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, 
   copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean);
   copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(vpad, m, (T*)var);
   return (int)hipGetLastError();
+}
+
+template <typename T>
+static int post_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* mean, void* cov,
+                    hipStream_t s) {
+  const long M = round_up(m, DGP_TILE_HOST);
+  const size_t e = sizeof(T);
+  char* w = (char*)work;
+  T* Xst = (T*)w; w += align_up(e * M * p->d);
+  T* Ks = (T*)w; w += align_up(e * (size_t)p->N * M);
+  T* V = (T*)w; w += align_up(e * (size_t)p->N * M);
+  T* kss = (T*)w; w += align_up(e * M);
+  T* mpad = (T*)w; w += align_up(e * M);
+  T* vpad = (T*)w;
+  int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s);
+  if (rc) return rc;
+  if ((rc = gram_diag<T>(p->model, p->d, Xst, M, (int)m, theta, kss, s))) return rc;
+  if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, mpad, vpad, s))) return rc;
+  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean);
+  hipError_t he = hipMemsetAsync(vpad, 0, e * M, s);  // zero "noise" for K(Xs, Xs)
+  if (he != hipSuccess) return (int)he;
+  if ((rc = gram_sym<T>(p->model, p->d, Xst, M, (int)m, theta, vpad, (T*)cov, s))) return rc;
+  return posterior_cov<T>(V, p->N, M, (T*)cov, s);
 }
 
 #define DGP_BY_DTYPE(p, CALL64, CALL32) ((p)->dtype == DGP_F64 ? (CALL64) : (CALL32))
@@ -315,6 +394,53 @@ int dgp_predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, voi
   int rc = DGP_BY_DTYPE(p, predict<double>(p, theta, Xs, m, work, mean, var, s),
                         predict<float>(p, theta, Xs, m, work, mean, var, s));
   return wrap(rc, "dgp_predict");
+}
+
+int dgp_posterior_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
+                      void* mean, void* cov, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!theta || !Xs || !work || !mean || !cov || m <= 0) return fail(DGP_E_ARG, "dgp_posterior_cov: null argument");
+  if (!p->have_factor) return fail(DGP_E_STATE, "dgp_posterior_cov: no factorisation in the plan (call dgp_factorize)");
+  if (work_bytes < dgp_predict_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_posterior_cov: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = DGP_BY_DTYPE(p, post_cov<double>(p, theta, Xs, m, work, mean, cov, s),
+                        post_cov<float>(p, theta, Xs, m, work, mean, cov, s));
+  return wrap(rc, "dgp_posterior_cov");
+}
+
+int dgp_plan_set_timing(dgp_plan* p, int enabled) {
+  if (!p) return fail(DGP_E_ARG, "null plan");
+  p->timing = enabled ? 1 : 0;
+  p->timed_valid = 0;
+  return 0;
+}
+
+int dgp_plan_get_timing(dgp_plan* p, double* ms_out) {
+  if (!p || !ms_out) return fail(DGP_E_ARG, "dgp_plan_get_timing: null argument");
+  if (!p->timing || !p->tev || !p->timed_valid)
+    return fail(DGP_E_STATE, "dgp_plan_get_timing: enable timing and run dgp_fit_step first");
+  static const int map[TS_COUNT] = {DGP_TIME_GRAM, DGP_TIME_POTRF, DGP_TIME_TRTRI, DGP_TIME_LAUUM, DGP_TIME_SOLVE,
+                                    DGP_TIME_GRAD};
+  for (int i = 0; i < DGP_TIME_COUNT; ++i) ms_out[i] = 0.0;
+  hipError_t e = hipEventSynchronize(p->tev[2 * TS_GRAD + 1]);
+  if (e != hipSuccess) return hipfail(e, "hipEventSynchronize");
+  for (int st = 0; st < TS_COUNT; ++st) {
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, p->tev[2 * st], p->tev[2 * st + 1]);
+    if (e != hipSuccess) return hipfail(e, "hipEventElapsedTime");
+    ms_out[map[st]] = ms;
+  }
+  double sum = 0.0;
+  for (int i = 0; i < p->n_syrk; ++i) {
+    float ms = 0.f;
+    e = hipEventSynchronize(p->sev[2 * i + 1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, p->sev[2 * i], p->sev[2 * i + 1]);
+    if (e != hipSuccess) return hipfail(e, "hipEventElapsedTime(syrk)");
+    sum += ms;
+  }
+  ms_out[DGP_TIME_SYRK_SUM] = sum;
+  ms_out[DGP_TIME_SYRK_N] = p->n_syrk;
+  return 0;
 }
 
 int dgp_stage_gram(dgp_plan* p, const double* theta, const void* noise, void* stream) {

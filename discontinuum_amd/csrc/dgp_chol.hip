@@ -36,18 +36,40 @@ __device__ __forceinline__ float rsqrt_nr(float d) {
   return y;
 }
 
+__device__ __forceinline__ double rcp_nr(double d) {
+  double y = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + 2 Newton steps
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  return y;
+}
+__device__ __forceinline__ float rcp_nr(float d) {
+  float y = __builtin_amdgcn_rcpf(d);
+  float e = fmaf(-d, y, 1.0f);
+  y = fmaf(y, e, y);
+  return y;
+}
+
 // ------------------------------------------------------------------------------------------
 // Diagonal block: 256 threads own the 128x128 block cyclically (thread (ti,tj) holds cells
-// (ti+16a, tj+16b)).  Step k of the sweep eliminates pivot k from the Schur complement (cells right of
-// column k) AND from the inverse being built in the cells left of it, so after 128 steps the lower
-// cells hold L_kk^-1.  One barrier per step; the pivot row/column travel through a double-buffered
-// 128-entry LDS vector.  L_kk columns / L_kk^-1 rows are streamed out as they become final.
+// (ti+16a, tj+16b), b <= a).  Step k of the sweep eliminates pivot k from the Schur complement (cells
+// right of column k) AND from the inverse being built in the cells left of it (in-place Gauss-Jordan),
+// so after 128 steps cell (i,j), j < i, holds (L_kk^-1)[i][j] / s_i with s_i = 1/sqrt(pivot_i).
+// Per step: one barrier, one LDS round trip (pivot row/column through a double-buffered 128-vector),
+// branch-free FMAs.  The reciprocal of the NEXT pivot is computed by its owner's wave only and
+// published with the vector.  Raw L columns are parked in global as they leave the registers and
+// scaled by s_k in the epilogue together with the inverse.
 template <typename T>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long ld, long k0, T* __restrict__ Tinv,
                                                          T* __restrict__ logdet, int* __restrict__ info) {
   __shared__ T vbuf[2][NB];
+  __shared__ T pinv[2];
   __shared__ T dvals[NB];
+  __shared__ T svals[NB];
+  __shared__ int bad;
   const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   T* Ablk = A + k0 * ld + k0;
   T* Xblk = Tinv + k0 * ld + k0;
   T reg[8][8];
@@ -59,6 +81,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long
 #pragma unroll
     for (int a = 0; a < 8; ++a) vbuf[0][ti + 16 * a] = reg[a][0];
   }
+  if (t == 0) {
+    pinv[0] = rcp_nr(reg[0][0]);
+    dvals[0] = reg[0][0];
+    bad = NB;
+  }
   __syncthreads();
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb) {
@@ -67,31 +94,22 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long
       const int k = kb * 16 + kt;
       const T* v = vbuf[k & 1];
       T* vn = vbuf[(k + 1) & 1];
-      const T d = v[k];
-      const T s = rsqrt_nr(d);
-      if (t == 0) {
-        dvals[k] = d;
-        if (!(d > T(0))) atomicCAS(info, 0, (int)(k0 + k + 1));
-      }
-      if (t < NB) {  // row k of L_kk^-1 (zeros right of the diagonal)
-        Xblk[(long)k * ld + t] = t < k ? v[t] * s : (t == k ? s : T(0));
-      } else {  // column k of L_kk, and zeros above the diagonal
-        const int i = t - NB;
-        if (i >= k) Ablk[(long)i * ld + k] = (i == k) ? d * s : v[i] * s;
-        if (i > k) Ablk[(long)k * ld + i] = T(0);
-      }
+      // every LDS read of the step is issued up front, unconditionally
+      T vi[8], vj[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) vi[a] = (a >= kb) ? v[ti + 16 * a] : T(0);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) vj[b] = v[tj + 16 * b];
+      const T inv_d = pinv[k & 1];
       // li = 0 on rows that are already final turns the update into unconditional FMAs
-      T li[8], vj[8];
+      T li[8];
 #pragma unroll
       for (int a = 0; a < 8; ++a) {
         const bool rowact = (a > kb) || (a == kb && ti > kt);
-        li[a] = rowact ? v[ti + 16 * a] * s : T(0);
+        li[a] = rowact ? vi[a] * inv_d : T(0);
       }
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int j = tj + 16 * b;
-        vj[b] = (j == k) ? s : v[j] * s;
-      }
+      const bool pivcol = (tj == kt);
+      vj[kb] = pivcol ? T(1) : vj[kb];
 #pragma unroll
       for (int a = 0; a < 8; ++a) {
         if (a < kb) continue;  // rows above the pivot block are final
@@ -99,83 +117,153 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long
         for (int b = 0; b < 8; ++b) {
           if (b > a) continue;
           T cur = reg[a][b];
-          if (b == kb) cur = (tj == kt) ? T(0) : cur;  // cell (i,k): Schur value consumed, inverse starts at 0
+          if (b == kb) cur = pivcol ? T(0) : cur;  // cell (i,k): Schur value consumed, inverse starts at 0
           reg[a][b] = fma(-li[a], vj[b], cur);
         }
       }
-      // publish pivot column k+1 (rows >= k+1) and pivot row k+1 (columns <= k) for the next step
-      if (kt < 15) {
-        const int k1 = k + 1, kt1 = kt + 1;
-        if (tj == kt1) {
-#pragma unroll
-          for (int a = 0; a < 8; ++a)
-            if (a >= kb && ti + 16 * a >= k1) vn[ti + 16 * a] = reg[a][kb];
+      if (k + 1 < NB) {
+        const int kt1 = (kt + 1) & 15;
+        const bool last = (kt == 15);
+        // reciprocal of the next pivot: only the wave that owns cell (k+1,k+1) runs the Newton chain
+        if (wave == ((17 * kt1) >> 6)) {
+          const T pc = last ? reg[(kb + 1) & 7][(kb + 1) & 7] : reg[kb][kb];
+          const T pi = rcp_nr(pc);
+          if (t == 17 * kt1) {
+            pinv[(k + 1) & 1] = pi;
+            dvals[k + 1] = pc;
+          }
         }
-        if (ti == kt1) {
+        // publish pivot column k+1 (rows >= k+1, also parked raw in global) and pivot row k+1 (cols <= k)
+        if (!last) {
+          if (tj == kt1) {
 #pragma unroll
-          for (int b = 0; b < 8; ++b)
-            if (b <= kb && tj + 16 * b < k1) vn[tj + 16 * b] = reg[kb][b];
-        }
-      } else if (kb < 7) {
-        if (tj == 0) {
+            for (int a = 0; a < 8; ++a)
+              if (a >= kb && ti + 16 * a >= k + 1) {
+                vn[ti + 16 * a] = reg[a][kb];
+                Ablk[(long)(ti + 16 * a) * ld + k + 1] = reg[a][kb];
+              }
+          }
+          if (ti == kt1) {
 #pragma unroll
-          for (int a = 0; a < 8; ++a)
-            if (a >= kb + 1) vn[ti + 16 * a] = reg[a][(kb + 1) & 7];
-        }
-        if (ti == 0) {
+            for (int b = 0; b < 8; ++b)
+              if (b <= kb && tj + 16 * b < k + 1) vn[tj + 16 * b] = reg[kb][b];
+          }
+        } else {
+          if (tj == 0) {
 #pragma unroll
-          for (int b = 0; b < 8; ++b)
-            if (b <= kb) vn[tj + 16 * b] = reg[(kb + 1) & 7][b];
+            for (int a = 0; a < 8; ++a)
+              if (a >= kb + 1) {
+                vn[ti + 16 * a] = reg[a][(kb + 1) & 7];
+                Ablk[(long)(ti + 16 * a) * ld + k + 1] = reg[a][(kb + 1) & 7];
+              }
+          }
+          if (ti == 0) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+              if (b <= kb) vn[tj + 16 * b] = reg[(kb + 1) & 7][b];
+          }
         }
       }
-      __syncthreads();
+      // LDS-only barrier: __syncthreads() would also drain the parked global stores (vmcnt(0)) every step
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
-  // log|L_kk|^2 = sum log(pivots); fixed-order tree so the result is reproducible
+  // epilogue: s_k = 1/sqrt(pivot_k); log-determinant; first bad pivot
   __shared__ T red[NB];
-  if (t < NB) red[t] = log(dvals[t]);
+  if (t < NB) {
+    const T d = dvals[t];
+    svals[t] = rsqrt_nr(d);
+    red[t] = log(d);
+    if (!(d > T(0))) atomicMin(&bad, t);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // parked L columns have left this CU
   __syncthreads();
   for (int sft = 64; sft > 0; sft >>= 1) {
     if (t < sft) red[t] += red[t + sft];
     __syncthreads();
   }
-  if (t == 0) logdet[0] += red[0];  // diag kernels of one factorisation run in stream order
+  if (t == 0) {
+    logdet[0] += red[0];  // diag kernels of one factorisation run in stream order
+    if (bad < NB) atomicCAS(info, 0, (int)(k0 + bad + 1));
+  }
+  // L_kk^-1 = diag(s) * cells ; L_kk = parked raw columns * s_k ; zeros above the diagonal
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int i = ti + 16 * a;
+    const T si = svals[i];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int j = tj + 16 * b;
+      T x = T(0);
+      if (b <= a) x = j < i ? reg[a][b] * si : (j == i ? si : T(0));
+      Xblk[(long)i * ld + j] = x;
+    }
+  }
+  // all loads before any store: the compiler cannot reorder a load across a may-alias store
+  T raw[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int i = ti + 16 * a, j = tj + 16 * b;
+      raw[a][b] = (b <= a && j <= i) ? __builtin_nontemporal_load(&Ablk[(long)i * ld + j]) : T(0);  // bypasses L1
+    }
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int i = ti + 16 * a, j = tj + 16 * b;
+      Ablk[(long)i * ld + j] = raw[a][b] * svals[j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// A[i,k] <- A[i,k] * L_kk^-T  (L_kk^-1 lives in the diagonal block of Tinv)
+// A[i,k] <- A[i,k] * L_kk^-T  (L_kk^-1 lives in the diagonal block of Tinv).  This kernel sits on the
+// sequential panel chain, so it uses 64x64 tiles: four times the workgroups, a quarter of the latency.
 template <typename T>
 __global__ __launch_bounds__(256) void trsm_kernel(T* __restrict__ A, const T* __restrict__ Tinv, long ld, int k) {
-  using G = TileGemm<T, true, true>;
+  // 64 rows x all 128 panel columns per workgroup: a workgroup only ever reads the rows it overwrites
+  using G = TileGemm<T, true, true, 64, 128>;
   __shared__ T smem[G::SMEM_ELEMS];
-  const long bi = k + 1 + blockIdx.x;
+  const long row0 = (long)(k + 1) * NB + (long)blockIdx.x * 64;
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
-  T* Ablk = A + bi * NB * ld + (long)k * NB;
-  G::run(Ablk, ld, Tinv + (long)k * NB * ld + (long)k * NB, ld, NB / 16, smem, acc);
-  G::foreach (acc, [&](int r, int c, T& v) { Ablk[(long)r * ld + c] = v; });
+  T* Arow = A + row0 * ld + (long)k * NB;
+  G::run(Arow, ld, Tinv + (long)k * NB * ld + (long)k * NB, ld, NB / 16, smem, acc);
+  G::foreach (acc, [&](int r, int c, T& v) { Arow[(long)r * ld + c] = v; });
 }
 
-// A[i,j] -= A[i,k] A[j,k]^T for the lower tiles with block column >= jbeg.
-// colmode: only block column jbeg (the lookahead column).
+// A[i,j] -= A[i,k] A[j,k]^T for the lower tiles with block column >= jbeg (bulk trailing update).
+// The accumulators start at -C, so the read of C overlaps the first operand loads and the epilogue
+// is store-only:  C_new = -( -C + P_i P_j^T ).
 template <typename T>
-__global__ __launch_bounds__(256) void syrk_kernel(T* __restrict__ A, long ld, int k, int jbeg, int colmode) {
+__global__ __launch_bounds__(256) void syrk_kernel(T* __restrict__ A, long ld, int k, int jbeg) {
   using G = TileGemm<T, true, true>;
   __shared__ T smem[G::SMEM_ELEMS];
   int bi, bj;
-  if (colmode) {
-    bi = jbeg + blockIdx.x;
-    bj = jbeg;
-  } else {
-    tri_decode(blockIdx.x, bi, bj);
-    bi += jbeg;
-    bj += jbeg;
-  }
+  tri_decode(blockIdx.x, bi, bj);
+  bi += jbeg;
+  bj += jbeg;
   typename G::acc_t acc[G::MI][G::NI];
-  G::zero(acc);
-  G::run(A + (long)bi * NB * ld + (long)k * NB, ld, A + (long)bj * NB * ld + (long)k * NB, ld, NB / 16, smem, acc);
   T* C = A + (long)bi * NB * ld + (long)bj * NB;
-  G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] -= v; });
+  G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * ld + c]; });
+  G::run(A + (long)bi * NB * ld + (long)k * NB, ld, A + (long)bj * NB * ld + (long)k * NB, ld, NB / 16, smem, acc);
+  G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] = -v; });
+}
+
+// the lookahead column: only block column jcol, 64x64 tiles (latency-critical, see trsm_kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int jcol) {
+  using G = TileGemm<T, true, true, 64, 64>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  const long row0 = (long)jcol * NB + (long)blockIdx.x * 64;
+  const long col0 = (long)jcol * NB + (long)blockIdx.y * 64;
+  if (col0 > row0 + 63) return;  // strictly upper 64x64 quadrant of the diagonal block
+  typename G::acc_t acc[G::MI][G::NI];
+  T* C = A + row0 * ld + col0;
+  G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * ld + c]; });
+  G::run(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, NB / 16, smem, acc);
+  G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] = -v; });
 }
 
 template <typename T>
@@ -185,7 +273,9 @@ __global__ void zero1_kernel(T* p, int* info) {
 }
 
 template <typename T>
-int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev) {
+int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
+          hipEvent_t* syrk_ev, int* n_syrk) {
+  int ns = 0;
   const int nbk = (int)(N / NB);
   zero1_kernel<T><<<1, 1, 0, s>>>(logdet, info);
   auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
@@ -193,35 +283,43 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     for (int k = 0; k < nbk; ++k) {
       potrf_diag_kernel<T><<<1, 256, 0, s>>>(A, N, (long)k * NB, Tinv, logdet, info);
       if (k + 1 < nbk) {
-        trsm_kernel<T><<<nbk - k - 1, 256, 0, s>>>(A, Tinv, N, k);
-        syrk_kernel<T><<<tri(nbk - k - 1), 256, 0, s>>>(A, N, k, k + 1, 0);
+        trsm_kernel<T><<<2 * (nbk - k - 1), 256, 0, s>>>(A, Tinv, N, k);
+        if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
+        syrk_kernel<T><<<tri(nbk - k - 1), 256, 0, s>>>(A, N, k, k + 1);
+        if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s);
+        ++ns;
       }
     }
+    if (n_syrk) *n_syrk = ns;
     return (int)hipGetLastError();
   }
   // one-panel lookahead: stream s carries the panel chain, s2 the bulk trailing updates.
   hipEvent_t* P = ev;        // P[k]: panel k (diag + trsm) ready
   hipEvent_t* U = ev + nbk;  // U[k]: bulk update with panel k done
   potrf_diag_kernel<T><<<1, 256, 0, s>>>(A, N, 0, Tinv, logdet, info);
-  trsm_kernel<T><<<nbk - 1, 256, 0, s>>>(A, Tinv, N, 0);
+  trsm_kernel<T><<<2 * (nbk - 1), 256, 0, s>>>(A, Tinv, N, 0);
   hipEventRecord(P[0], s);
   int last_u = -1;
   for (int k = 0; k + 1 < nbk; ++k) {
     if (k + 2 < nbk) {
       hipStreamWaitEvent(s2, P[k], 0);
-      syrk_kernel<T><<<tri(nbk - k - 2), 256, 0, s2>>>(A, N, k, k + 2, 0);
+      if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
+      syrk_kernel<T><<<tri(nbk - k - 2), 256, 0, s2>>>(A, N, k, k + 2);
+      if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
+      ++ns;
       hipEventRecord(U[k], s2);
       last_u = k;
     }
     if (k >= 1) hipStreamWaitEvent(s, U[k - 1], 0);
-    syrk_kernel<T><<<nbk - k - 1, 256, 0, s>>>(A, N, k, k + 1, 1);
+    syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k, k + 1);
     potrf_diag_kernel<T><<<1, 256, 0, s>>>(A, N, (long)(k + 1) * NB, Tinv, logdet, info);
     if (k + 2 < nbk) {
-      trsm_kernel<T><<<nbk - k - 2, 256, 0, s>>>(A, Tinv, N, k + 1);
+      trsm_kernel<T><<<2 * (nbk - k - 2), 256, 0, s>>>(A, Tinv, N, k + 1);
       hipEventRecord(P[k + 1], s);
     }
   }
   if (last_u >= 0) hipStreamWaitEvent(s, U[last_u], 0);
+  if (n_syrk) *n_syrk = ns;
   return (int)hipGetLastError();
 }
 
@@ -235,7 +333,9 @@ __global__ __launch_bounds__(256) void trtri_level_kernel(const T* __restrict__ 
   using G = TileGemm<T, true, false>;
   __shared__ T smem[G::SMEM_ELEMS];
   const int lo = 2 * m * blockIdx.y, mid = lo + m, hi = min(lo + 2 * m, nbk);
-  const int i = mid + blockIdx.x / m, j = lo + blockIdx.x % m;
+  // longest k-range first: W-step K ~ (mid - j), T-step K ~ (i - mid + 1)
+  const int i = STEP == 0 ? mid + blockIdx.x % m : mid + (m - 1 - blockIdx.x / m);
+  const int j = STEP == 0 ? lo + blockIdx.x / m : lo + blockIdx.x % m;
   if (i >= hi) return;
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
@@ -419,8 +519,30 @@ int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, 
   return (int)hipGetLastError();
 }
 
+// cov[i,j] = Kss[i,j] - sum_k V[k,i] V[k,j]  (i >= j tiles), k over all N rows of V (N x M)
+template <typename T>
+__global__ __launch_bounds__(256) void posterior_cov_kernel(const T* __restrict__ V, long N, long M, T* __restrict__ cov) {
+  using G = TileGemm<T, false, false>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  int bi, bj;
+  tri_decode(blockIdx.x, bi, bj);
+  typename G::acc_t acc[G::MI][G::NI];
+  T* C = cov + (long)bi * NB * M + (long)bj * NB;
+  G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * M + c]; });
+  G::run(V + (long)bi * NB, M, V + (long)bj * NB, M, (int)(N / 16), smem, acc);
+  G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * M + c] = -v; });
+}
+
+template <typename T>
+int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s) {
+  const int nb = (int)(M / NB);
+  posterior_cov_kernel<T><<<(unsigned)(nb * (nb + 1) / 2), 256, 0, s>>>(V, N, M, cov);
+  return (int)hipGetLastError();
+}
+
 #define DGP_INST(T)                                                                                              \
-  template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*);                     \
+  template int posterior_cov<T>(const T*, long, long, T*, hipStream_t);                                          \
+  template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*);                     \
   template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t);                                          \
   template int lauum<T>(const T*, long, T*, hipStream_t);                                                        \
   template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t);                             \

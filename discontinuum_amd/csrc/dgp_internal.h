@@ -27,7 +27,8 @@ long gram_grad_partials(long N);  // number of T elements `partials` must hold
 
 // ---- dgp_chol.hip ---------------------------------------------------------------------------
 template <typename T>
-int potrf(T* A, long N, T* Dinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev);
+int potrf(T* A, long N, T* Dinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
+          hipEvent_t* syrk_ev /* 2 per bulk launch, or null */, int* n_syrk);
 template <typename T>
 int trtri(const T* L, const T* Dinv, long N, T* Tm, T* W, hipStream_t s);
 template <typename T>
@@ -40,5 +41,8 @@ template <typename T>
 int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* mean, T* var,
                 hipStream_t s);
 long solve_partials(long N);
+// cov (M x M) = Kss - V^T V, lower tiles; Kss already holds K(Xs, Xs) (identity pad)
+template <typename T>
+int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s);
 
 }  // namespace dgp

@@ -1,0 +1,47 @@
+"""Hyperparameter priors with gpytorch's log-densities.
+
+Each prior is evaluated on the CONSTRAINED value and summed over ARD dimensions, exactly like the
+``Sum_priors log p(theta)`` term that ``ExactMarginalLogLikelihood`` adds
+(reference call site: ``src/discontinuum/engines/gpytorch.py:318, 353``).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+_LOG2PI = math.log(2.0 * math.pi)
+
+
+class Prior(nn.Module):
+    def log_prob(self, x):  # pragma: no cover - interface
+        raise NotImplementedError
+
+
+class NormalPrior(Prior):
+    def __init__(self, loc, scale):
+        super().__init__()
+        self.loc, self.scale = float(loc), float(scale)
+
+    def log_prob(self, x):
+        return -0.5 * ((x - self.loc) / self.scale) ** 2 - math.log(self.scale) - 0.5 * _LOG2PI
+
+
+class HalfNormalPrior(Prior):
+    def __init__(self, scale):
+        super().__init__()
+        self.scale = float(scale)
+
+    def log_prob(self, x):
+        return math.log(2.0) - 0.5 * (x / self.scale) ** 2 - math.log(self.scale) - 0.5 * _LOG2PI
+
+
+class GammaPrior(Prior):
+    def __init__(self, concentration, rate):
+        super().__init__()
+        self.concentration, self.rate = float(concentration), float(rate)
+
+    def log_prob(self, x):
+        a, b = self.concentration, self.rate
+        return a * math.log(b) - math.lgamma(a) + (a - 1.0) * torch.log(x) - b * x

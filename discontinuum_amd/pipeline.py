@@ -1,0 +1,215 @@
+"""Data transformations between raw and model space.
+
+Behaviour follows ``src/discontinuum/pipeline.py:14-403``: the same named pipelines with the same
+step order, clips and scalers, written on plain numpy (no sklearn ``Pipeline`` dependency) and on the
+``xr_compat`` labelled arrays.  Known answer pinned by the reference's own test
+(``src/discontinuum/tests/test_pipeline.py:14``) is checked in ``tests/test_pipeline.py``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+from scipy.stats import norm
+
+from .xr_compat import DataArray
+
+
+def datetime_to_decimal_year(x):
+    """datetime64 array -> year + (julian day - julian day of 1 Jan) / days in year."""
+    x = np.asarray(x)
+    if not np.issubdtype(x.dtype, np.datetime64):
+        raise ValueError("Array must contain numpy datetime64 objects.")
+    stamp = pd.to_datetime(x.reshape(-1))
+    jan1 = pd.to_datetime(stamp.year, format="%Y")
+    length = 365 + stamp.is_leap_year
+    frac = (stamp.to_julian_date() - jan1.to_julian_date()) / length
+    return (stamp.year + frac).to_numpy()
+
+
+def decimal_year_to_datetime(x):
+    x = np.asarray(x, dtype=float)
+    whole = np.floor(x).astype(int)
+    jan1 = pd.to_datetime(whole, format="%Y")
+    length = 365 + jan1.is_leap_year
+    stamp = jan1 + pd.to_timedelta((x - whole) * length, unit="D")
+    return stamp.round("1s").to_numpy()
+
+
+class _Step:
+    def fit(self, X):
+        return self
+
+    def transform(self, X):
+        return X
+
+    def inverse_transform(self, X):
+        return X
+
+
+class MetadataManager(_Step):
+    """Strip / restore the labelled-array wrapper (attrs, name, dims)."""
+
+    def fit(self, X):
+        self.attrs_, self.name_, self.dims_ = X.attrs, X.name, X.dims
+        return self
+
+    def transform(self, X):
+        return np.asarray(X.values).reshape(-1, 1)
+
+    def inverse_transform(self, X):
+        return DataArray(np.squeeze(X), attrs=self.attrs_, name=self.name_, dims=self.dims_)
+
+
+class ClipTransformer(_Step):
+    def __init__(self, min=None, max=None):  # noqa: A002
+        self.min, self.max = min, max
+
+    def transform(self, X):
+        return np.clip(X, a_min=self.min, a_max=self.max)
+
+    inverse_transform = transform
+
+
+class LogTransformer(_Step):
+    def transform(self, X):
+        return np.log(X)
+
+    def inverse_transform(self, X):
+        return np.exp(X)
+
+
+class SquareTransformer(_Step):
+    def transform(self, X):
+        return X ** 2
+
+    def inverse_transform(self, X):
+        return np.sqrt(X)
+
+
+class UnitScaler(_Step):
+    def __init__(self, zero_value=0):
+        self.zero = zero_value
+
+    def fit(self, X):
+        self.min_, self.max_ = X.min(), X.max()
+        return self
+
+    def transform(self, X):
+        return self.zero + (X - self.min_) / (self.max_ - self.min_)
+
+    def inverse_transform(self, X):
+        return self.min_ + (X - self.zero) * (self.max_ - self.min_)
+
+
+class StandardScaler(_Step):
+    def __init__(self, with_mean=True, with_std=True):
+        self.with_mean, self.with_std = with_mean, with_std
+
+    def fit(self, X):
+        if self.with_mean:
+            self.mean_ = X.mean(axis=0)
+        if self.with_std:
+            self.scale_ = X.std(axis=0)
+        return self
+
+    def transform(self, X):
+        if self.with_mean:
+            X = X - self.mean_
+        if self.with_std:
+            X = X / self.scale_
+        return X
+
+    def inverse_transform(self, X):
+        if self.with_std:
+            X = X * self.scale_
+        if self.with_mean:
+            X = X + self.mean_
+        return X
+
+
+class TimeTransformer(_Step):
+    def transform(self, X):
+        return datetime_to_decimal_year(X)
+
+    def inverse_transform(self, X):
+        return decimal_year_to_datetime(X)
+
+
+class Pipeline:
+    """fit() threads the data through the steps; inverse_transform() walks them backwards."""
+
+    def __init__(self, steps):
+        self.steps = list(steps)
+
+    def fit(self, X):
+        for _name, step in self.steps:
+            X = step.fit(X).transform(X)
+        return self
+
+    def transform(self, X):
+        for _name, step in self.steps:
+            X = step.transform(X)
+        return X
+
+    def inverse_transform(self, X):
+        for _name, step in reversed(self.steps):
+            X = step.inverse_transform(X)
+        return X
+
+
+class LogStandardPipeline(Pipeline):
+    def __init__(self):
+        super().__init__([("metadata", MetadataManager()), ("clip", ClipTransformer(min=1e-6)),
+                          ("log", LogTransformer()), ("scaler", StandardScaler())])
+
+
+class NoOpPipeline(Pipeline):
+    def __init__(self):
+        super().__init__([("metadata", MetadataManager()), ("clip", ClipTransformer(min=0))])
+
+
+class StandardPipeline(Pipeline):
+    def __init__(self):
+        super().__init__([("metadata", MetadataManager()), ("clip", ClipTransformer(min=0)),
+                          ("scaler", StandardScaler())])
+
+
+class UnitPipeline(Pipeline):
+    def __init__(self):
+        super().__init__([("metadata", MetadataManager()), ("clip", ClipTransformer(min=0)),
+                          ("scaler", UnitScaler(zero_value=1))])
+
+
+class TimePipeline(Pipeline):
+    def __init__(self):
+        super().__init__([("metadata", MetadataManager()), ("decimal_year", TimeTransformer()),
+                          ("scaler", StandardScaler(with_std=False))])
+
+
+def _zscore(ci):
+    return norm.ppf(1 - (1 - ci) / 2)
+
+
+class StandardErrorPipeline(Pipeline):
+    """inverse_transform turns a model-space variance into a standard error."""
+
+    def __init__(self):
+        super().__init__([("metadata", MetadataManager()), ("scaler", StandardScaler(with_mean=False)),
+                          ("square", SquareTransformer()), ("clip", ClipTransformer(min=0))])
+
+    def ci(self, mean, se, ci=0.95):
+        half = se * _zscore(ci)
+        return mean - half, mean + half
+
+
+class LogErrorPipeline(Pipeline):
+    """inverse_transform turns a log-space variance into a geometric standard error."""
+
+    def __init__(self):
+        super().__init__([("metadata", MetadataManager()), ("log", LogTransformer()),
+                          ("scaler", StandardScaler(with_mean=False)), ("square", SquareTransformer()),
+                          ("clip", ClipTransformer(min=1e-6))])
+
+    def ci(self, mean, se, ci=0.95):
+        factor = se ** _zscore(ci)
+        return mean / factor, mean * factor

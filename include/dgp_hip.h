@@ -52,6 +52,7 @@ extern "C" {
 #define DGP_BUF_S 3     /* K^^-1 (lower) */
 #define DGP_BUF_Z 4     /* L^-1 r */
 #define DGP_BUF_ALPHA 5 /* K^^-1 r */
+#define DGP_BUF_INFO 6  /* int32: info of the last factorisation */
 
 typedef struct dgp_plan dgp_plan;
 
@@ -100,6 +101,28 @@ size_t dgp_predict_workspace_bytes(const dgp_plan* plan, int64_t m);
  * Replaces `self.likelihood(self.model(x))` .mean/.variance at engines/gpytorch.py:621-624. */
 int dgp_predict(dgp_plan* plan, const double* theta_host, const void* Xs_dev, int64_t m, void* work_dev,
                 size_t work_bytes, void* mean_dev, void* var_dev, void* stream);
+
+/* Full latent posterior covariance for sample() (engines/gpytorch.py:575-580):
+ *   cov_dev (M x M row-major, M = dgp_padded_n(m), lower triangle valid, identity pad)
+ *     = K(Xs, Xs) - V^T V,  V = L^-1 K(X, Xs);   mean_dev[j] = K(x*_j, X) alpha  (m entries).
+ * work_dev as for dgp_predict (dgp_predict_workspace_bytes). */
+int dgp_posterior_cov(dgp_plan* plan, const double* theta_host, const void* Xs_dev, int64_t m, void* work_dev,
+                      size_t work_bytes, void* mean_dev, void* cov_dev, void* stream);
+
+/* In-library HIP-event timing of the stages of dgp_fit_step (events are recorded on the stream each
+ * kernel is launched on, including the internal lookahead stream).  dgp_plan_get_timing synchronises
+ * on the events of the most recent fit step and fills ms_out[DGP_TIME_COUNT]. */
+#define DGP_TIME_GRAM 0      /* gram_sym kernel */
+#define DGP_TIME_POTRF 1     /* whole factorisation, wall time on the caller's stream */
+#define DGP_TIME_SYRK_SUM 2  /* sum of the bulk trailing-update (syrk) launches */
+#define DGP_TIME_SYRK_N 3    /* number of those launches */
+#define DGP_TIME_TRTRI 4     /* all trtri level launches */
+#define DGP_TIME_LAUUM 5     /* lauum kernel */
+#define DGP_TIME_SOLVE 6     /* triangular solves */
+#define DGP_TIME_GRAD 7      /* gram_grad + reduction */
+#define DGP_TIME_COUNT 8
+int dgp_plan_set_timing(dgp_plan* plan, int enabled);
+int dgp_plan_get_timing(dgp_plan* plan, double* ms_out);
 
 /* ---- single stages on the plan buffers, for parity tests and per-kernel profiling ---- */
 int dgp_stage_gram(dgp_plan* plan, const double* theta_host, const void* noise_dev, void* stream);

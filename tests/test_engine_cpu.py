@@ -1,0 +1,176 @@
+"""Host logic of the engine on CPU: lowering, constraints, priors, objective assembly, fit loop,
+prediction wrappers and checkpointing -- with the device plan replaced by an oracle-backed double."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from discontinuum_amd.engines.hip import MarginalHIP
+from discontinuum_amd.gp import kernels as K
+from discontinuum_amd.gp.lowering import UnsupportedKernelError, lower
+from discontinuum_amd.gp.mll import ExactMarginalLogLikelihood
+from discontinuum_amd.loadest_gp import LoadestGP
+from discontinuum_amd.rating_gp import RatingGP
+from oracle import gp_oracle as orc
+from tests.helpers import OraclePlan, loadest_dataset, rating_dataset
+
+
+@pytest.fixture(autouse=True)
+def cpu_engine(monkeypatch):
+    monkeypatch.setattr(MarginalHIP, "_plan_factory", staticmethod(OraclePlan))
+    monkeypatch.setattr(MarginalHIP, "device", "cpu")
+    torch.manual_seed(0)
+
+
+def _loadest_raw_from_model(m):
+    """Flatten the model's raw parameters in oracle order."""
+    cm = m.model.covar_module
+    s0, s1, s2 = cm.kernels
+    per, m52 = s0.base_kernel.kernels
+    return torch.cat([v.detach().reshape(-1) for v in (
+        m.model.mean_module.raw_constant, s0.raw_outputscale, per.raw_lengthscale, per.raw_period_length,
+        m52.raw_lengthscale, s1.raw_outputscale, s1.base_kernel.raw_lengthscale, s2.raw_outputscale,
+        s2.base_kernel.raw_lengthscale)])
+
+
+def test_loadest_objective_and_gradient_match_oracle():
+    cov, tgt = loadest_dataset(60)
+    m = LoadestGP()
+    m.fit(cov, tgt, iterations=1)
+    # perturb so that no parameter sits at its initial value
+    with torch.no_grad():
+        for p in m.model.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    m.model.zero_grad(set_to_none=True)  # the training iteration left its gradients behind
+    mll = ExactMarginalLogLikelihood(m.likelihood, m.model)
+    obj = -mll(m._prior(), m._train_y)
+    assert obj.shape == (1,)
+    obj.sum().backward()
+    raw = _loadest_raw_from_model(m).clone().requires_grad_(True)
+    o = orc.LoadestOracle(2)
+    ref = o.objective(raw, torch.tensor(m.X), torch.tensor(m.y))
+    ref.backward()
+    assert abs(obj.item() - ref.item()) < 1e-12 * max(1, abs(ref.item()))
+    got = torch.cat([p.grad.reshape(-1) for p in (
+        m.model.mean_module.raw_constant, *[q for q in m.model.covar_module.parameters()])])
+    assert torch.allclose(got, raw.grad, rtol=1e-9, atol=1e-12)
+
+
+def test_rating_objective_matches_oracle():
+    cov, tgt, unc = rating_dataset(50)
+    m = RatingGP()
+    m.fit(cov, tgt, target_unc=unc, iterations=1)
+    mll = ExactMarginalLogLikelihood(m.likelihood, m.model)
+    obj = -mll(m._prior(), m._train_y)
+    mod = m.model
+    X, y, yu = torch.tensor(m.X), torch.tensor(m.y), torch.tensor(m.y_unc)
+    o = orc.RatingOracle.from_stage(X[:, 1])
+    name, theta_fn = lower(mod.covar_module, 2)
+    assert name == "rating"
+    theta = theta_fn().detach()
+    raw = torch.zeros(20, dtype=torch.float64)
+    raw[0], raw[1], raw[2] = mod.powerlaw.a.item(), mod.powerlaw.b.item(), mod.powerlaw.c.item()
+    raw[3] = m.likelihood.second_noise_covar.raw_noise.item()
+    raw[4] = orc.inv_interval(theta[0], o.b_lo, o.b_hi)
+    raw[5:] = orc.inv_softplus(theta[1:])
+    ref = o.objective(raw, X, y, yu)
+    assert abs(obj.item() - ref.item()) < 1e-10 * max(1, abs(ref.item()))
+
+
+def test_fit_reduces_objective_and_predicts():
+    cov, tgt = loadest_dataset(50)
+    m = LoadestGP()
+    assert not m.is_fitted
+    with pytest.raises(RuntimeError, match="hasn't been fitted"):
+        m.predict(cov)
+    m.fit(cov, tgt, iterations=15)
+    assert m.is_fitted and m._current_iteration == 14
+    mll = ExactMarginalLogLikelihood(m.likelihood, m.model)
+    after = -mll(m._prior(), m._train_y).item()
+    fresh = LoadestGP()
+    fresh.fit(cov, tgt, iterations=1)
+    with torch.no_grad():
+        for p in fresh.model.parameters():
+            p.zero_()
+    before = -ExactMarginalLogLikelihood(fresh.likelihood, fresh.model)(fresh._prior(), fresh._train_y).item()
+    assert after < before
+    target, se = m.predict(cov)
+    assert target.values.shape == (50,) and se.values.shape == (50,)
+    assert np.all(np.isfinite(target.values)) and np.all(se.values >= 1.0)  # GSE >= 1
+    # model-space parity of the prediction wrapper with the oracle
+    raw = _loadest_raw_from_model(m)
+    mu_ref, var_ref = orc.LoadestOracle(2).predict(raw, torch.tensor(m.X), torch.tensor(m.y), torch.tensor(m.X))
+    mu, var = m._model_space_predict(torch.tensor(m.X))
+    assert torch.allclose(mu, mu_ref, atol=1e-9) and torch.allclose(var, var_ref, atol=1e-9)
+    grid = m.predict_grid("flow")
+    assert grid.values.shape[1] == 18
+    draws = m.sample(cov, n=7)
+    assert draws.values.shape == (7, 50)
+
+
+def test_unsupported_optimizer_and_resume():
+    cov, tgt = loadest_dataset(30)
+    m = LoadestGP()
+    with pytest.raises(ValueError, match="Unsupported optimizer"):
+        m.fit(cov, tgt, iterations=2, optimizer="sgd")
+    m.fit(cov, tgt, iterations=4, optimizer="adamw")
+    calls = m._plan.calls
+    m.fit(cov, tgt, iterations=4, resume=True)  # nothing left to do
+    m.fit(cov, tgt, iterations=6, resume=True)
+    assert m._current_iteration == 5 and m._plan.calls > calls
+
+
+def test_save_load_roundtrip():
+    cov, tgt = loadest_dataset(30)
+    m = LoadestGP()
+    with pytest.raises(RuntimeError, match="No model to save"):
+        m.save(io.BytesIO())
+    m.fit(cov, tgt, iterations=3)
+    buf = io.BytesIO()
+    m.save(buf, extra={"site": "x"})
+    buf.seek(0)
+    m2 = LoadestGP.load(buf, cov, tgt)
+    assert m2.is_fitted and m2._current_iteration == 2
+    for a, b in zip(m.model.parameters(), m2.model.parameters()):
+        assert torch.equal(a, b)
+    t1, _ = m.predict(cov)
+    t2, _ = m2.predict(cov)
+    assert np.allclose(t1.values, t2.values)
+    m2.fit(cov, tgt, iterations=5, resume=True)  # continues from the checkpointed iteration
+
+
+def test_rating_fit_and_predict():
+    cov, tgt, unc = rating_dataset(40)
+    m = RatingGP()
+    m.fit(cov, tgt, target_unc=unc, iterations=5)
+    assert m.is_fitted
+    target, se = m.predict(cov)
+    assert np.all(np.isfinite(target.values))
+    b = m.model.powerlaw.b.item()
+    assert 1.2 <= b <= 2.5
+    with pytest.raises(NotImplementedError):
+        m.fit(cov, tgt, target_unc=unc, iterations=2, monotonic_penalty_weight=0.5)
+
+
+def test_lowering_rejects_other_structures():
+    k = K.ScaleKernel(K.RBFKernel(active_dims=[0])) + K.ScaleKernel(K.RBFKernel(active_dims=[1]))
+    with pytest.raises(UnsupportedKernelError):
+        lower(k, 2)
+    with pytest.raises(UnsupportedKernelError):
+        lower(K.ScaleKernel(K.RBFKernel()), 2)
+
+
+def test_nan_objective_guard():
+    """More than 10 consecutive failing objective evaluations re-raise (engines/gpytorch.py:352-358)."""
+    cov, tgt = loadest_dataset(20)
+    m = LoadestGP()
+    m.fit(cov, tgt, iterations=1)
+
+    def boom(*a, **k):
+        raise RuntimeError("not psd")
+
+    m._plan.fit_step = boom
+    with pytest.raises(RuntimeError, match="not psd"):
+        m.fit(cov, tgt, iterations=30, resume=True)
+    assert m.is_fitted
