@@ -60,7 +60,13 @@ def cpu_baseline(n, d, dtype_name, budget_s=45.0):
     n <= target whose cubic extrapolation fits the budget."""
     from oracle import gp_oracle as orc
 
-    cores = os.cpu_count() or 1
+    # the GPU box exposes many more hardware threads than the job's CPU share; oversubscribing torch's
+    # intra-op pool makes the dense linear algebra slower, not faster, so cap the pool
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
     torch.set_num_threads(cores)
 
     def one(nn):

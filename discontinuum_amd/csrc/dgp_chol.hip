@@ -60,84 +60,88 @@ __device__ __forceinline__ float rcp_nr(float d) {
 // branch-free FMAs.  The reciprocal of the NEXT pivot is computed by its owner's wave only and
 // published with the vector.  Raw L columns are parked in global as they leave the registers and
 // scaled by s_k in the epilogue together with the inverse.
-template <typename T>
+template <typename T, int BS>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long ld, long k0, T* __restrict__ Tinv,
                                                          T* __restrict__ logdet, int* __restrict__ info) {
-  __shared__ T vbuf[2][NB];
+  constexpr int NR = BS / 16;
+  __shared__ T vbuf[2][BS];
   __shared__ T pinv[2];
-  __shared__ T dvals[NB];
-  __shared__ T svals[NB];
+  __shared__ T dvals[BS];
+  __shared__ T svals[BS];
   __shared__ int bad;
   const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   T* Ablk = A + k0 * ld + k0;
   T* Xblk = Tinv + k0 * ld + k0;
-  T reg[8][8];
+  T reg[NR][NR];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < NR; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) reg[a][b] = (b <= a) ? Ablk[(long)(ti + 16 * a) * ld + tj + 16 * b] : T(0);
+    for (int b = 0; b < NR; ++b) reg[a][b] = (b <= a) ? Ablk[(long)(ti + 16 * a) * ld + tj + 16 * b] : T(0);
   if (tj == 0) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) vbuf[0][ti + 16 * a] = reg[a][0];
+    for (int a = 0; a < NR; ++a) vbuf[0][ti + 16 * a] = reg[a][0];
   }
   if (t == 0) {
     pinv[0] = rcp_nr(reg[0][0]);
     dvals[0] = reg[0][0];
-    bad = NB;
+    bad = BS;
   }
   __syncthreads();
 #pragma unroll
-  for (int kb = 0; kb < 8; ++kb) {
+  for (int kb = 0; kb < NR; ++kb) {
 #pragma unroll 1
     for (int kt = 0; kt < 16; ++kt) {
       const int k = kb * 16 + kt;
       const T* v = vbuf[k & 1];
       T* vn = vbuf[(k + 1) & 1];
       // every LDS read of the step is issued up front, unconditionally
-      T vi[8], vj[8];
+      T vi[NR], vj[NR];
 #pragma unroll
-      for (int a = 0; a < 8; ++a) vi[a] = (a >= kb) ? v[ti + 16 * a] : T(0);
+      for (int a = 0; a < NR; ++a) vi[a] = (a >= kb) ? v[ti + 16 * a] : T(0);
 #pragma unroll
-      for (int b = 0; b < 8; ++b) vj[b] = v[tj + 16 * b];
+      for (int b = 0; b < NR; ++b) vj[b] = v[tj + 16 * b];
       const T inv_d = pinv[k & 1];
       // li = 0 on rows that are already final turns the update into unconditional FMAs
-      T li[8];
+      T li[NR];
 #pragma unroll
-      for (int a = 0; a < 8; ++a) {
+      for (int a = 0; a < NR; ++a) {
         const bool rowact = (a > kb) || (a == kb && ti > kt);
         li[a] = rowact ? vi[a] * inv_d : T(0);
       }
       const bool pivcol = (tj == kt);
       vj[kb] = pivcol ? T(1) : vj[kb];
+      const bool last = (kt == 15);
+      const int kt1 = (kt + 1) & 15;
+      // The cell that becomes the NEXT pivot is updated first and its reciprocal's Newton chain is
+      // issued unconditionally (in the same basic block), so the scheduler can hide it under the bulk
+      // FMAs below; only the owner thread's value is published.
+      const T c0 = pivcol ? T(0) : reg[kb][kb];
+      const T upd_same = fma(-li[kb], vj[kb], c0);  // cell (k+1,k+1) while it is in 16-block kb
+      const T upd_next = fma(-li[(kb + 1) % NR], vj[(kb + 1) % NR], reg[(kb + 1) % NR][(kb + 1) % NR]);
+      const T pc = last ? upd_next : upd_same;
+      const T pi = rcp_nr(pc);
 #pragma unroll
-      for (int a = 0; a < 8; ++a) {
+      for (int a = 0; a < NR; ++a) {
         if (a < kb) continue;  // rows above the pivot block are final
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < NR; ++b) {
           if (b > a) continue;
           T cur = reg[a][b];
           if (b == kb) cur = pivcol ? T(0) : cur;  // cell (i,k): Schur value consumed, inverse starts at 0
           reg[a][b] = fma(-li[a], vj[b], cur);
         }
       }
-      if (k + 1 < NB) {
-        const int kt1 = (kt + 1) & 15;
-        const bool last = (kt == 15);
-        // reciprocal of the next pivot: only the wave that owns cell (k+1,k+1) runs the Newton chain
-        if (wave == ((17 * kt1) >> 6)) {
-          const T pc = last ? reg[(kb + 1) & 7][(kb + 1) & 7] : reg[kb][kb];
-          const T pi = rcp_nr(pc);
-          if (t == 17 * kt1) {
-            pinv[(k + 1) & 1] = pi;
-            dvals[k + 1] = pc;
-          }
+      if (k + 1 < BS) {
+        if (t == 17 * kt1) {
+          pinv[(k + 1) & 1] = pi;
+          dvals[k + 1] = pc;
         }
         // publish pivot column k+1 (rows >= k+1, also parked raw in global) and pivot row k+1 (cols <= k)
         if (!last) {
           if (tj == kt1) {
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < NR; ++a)
               if (a >= kb && ti + 16 * a >= k + 1) {
                 vn[ti + 16 * a] = reg[a][kb];
                 Ablk[(long)(ti + 16 * a) * ld + k + 1] = reg[a][kb];
@@ -145,22 +149,22 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long
           }
           if (ti == kt1) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
+            for (int b = 0; b < NR; ++b)
               if (b <= kb && tj + 16 * b < k + 1) vn[tj + 16 * b] = reg[kb][b];
           }
-        } else {
+        } else if (kb + 1 < NR) {
           if (tj == 0) {
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < NR; ++a)
               if (a >= kb + 1) {
-                vn[ti + 16 * a] = reg[a][(kb + 1) & 7];
-                Ablk[(long)(ti + 16 * a) * ld + k + 1] = reg[a][(kb + 1) & 7];
+                vn[ti + 16 * a] = reg[a][(kb + 1) % NR];
+                Ablk[(long)(ti + 16 * a) * ld + k + 1] = reg[a][(kb + 1) % NR];
               }
           }
           if (ti == 0) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
-              if (b <= kb) vn[tj + 16 * b] = reg[(kb + 1) & 7][b];
+            for (int b = 0; b < NR; ++b)
+              if (b <= kb) vn[tj + 16 * b] = reg[(kb + 1) % NR][b];
           }
         }
       }
@@ -169,8 +173,8 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long
     }
   }
   // epilogue: s_k = 1/sqrt(pivot_k); log-determinant; first bad pivot
-  __shared__ T red[NB];
-  if (t < NB) {
+  __shared__ T red[BS];
+  if (t < BS) {
     const T d = dvals[t];
     svals[t] = rsqrt_nr(d);
     red[t] = log(d);
@@ -178,21 +182,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // parked L columns have left this CU
   __syncthreads();
-  for (int sft = 64; sft > 0; sft >>= 1) {
+  for (int sft = BS / 2; sft > 0; sft >>= 1) {
     if (t < sft) red[t] += red[t + sft];
     __syncthreads();
   }
   if (t == 0) {
     logdet[0] += red[0];  // diag kernels of one factorisation run in stream order
-    if (bad < NB) atomicCAS(info, 0, (int)(k0 + bad + 1));
+    if (bad < BS) atomicCAS(info, 0, (int)(k0 + bad + 1));
   }
   // L_kk^-1 = diag(s) * cells ; L_kk = parked raw columns * s_k ; zeros above the diagonal
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < NR; ++a) {
     const int i = ti + 16 * a;
     const T si = svals[i];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NR; ++b) {
       const int j = tj + 16 * b;
       T x = T(0);
       if (b <= a) x = j < i ? reg[a][b] * si : (j == i ? si : T(0));
@@ -200,18 +204,18 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long
     }
   }
   // all loads before any store: the compiler cannot reorder a load across a may-alias store
-  T raw[8][8];
+  T raw[NR][NR];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < NR; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NR; ++b) {
       const int i = ti + 16 * a, j = tj + 16 * b;
       raw[a][b] = (b <= a && j <= i) ? __builtin_nontemporal_load(&Ablk[(long)i * ld + j]) : T(0);  // bypasses L1
     }
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < NR; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NR; ++b) {
       const int i = ti + 16 * a, j = tj + 16 * b;
       Ablk[(long)i * ld + j] = raw[a][b] * svals[j];
     }
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long
 // A[i,k] <- A[i,k] * L_kk^-T  (L_kk^-1 lives in the diagonal block of Tinv).  This kernel sits on the
 // sequential panel chain, so it uses 64x64 tiles: four times the workgroups, a quarter of the latency.
 template <typename T>
-__global__ __launch_bounds__(256) void trsm_kernel(T* __restrict__ A, const T* __restrict__ Tinv, long ld, int k) {
+__global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T* __restrict__ Tinv, long ld, int k) {
   // 64 rows x all 128 panel columns per workgroup: a workgroup only ever reads the rows it overwrites
   using G = TileGemm<T, true, true, 64, 128>;
   __shared__ T smem[G::SMEM_ELEMS];
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(T* __restrict__ A, const T* _
 // The accumulators start at -C, so the read of C overlaps the first operand loads and the epilogue
 // is store-only:  C_new = -( -C + P_i P_j^T ).
 template <typename T>
-__global__ __launch_bounds__(256) void syrk_kernel(T* __restrict__ A, long ld, int k, int jbeg) {
+__global__ __launch_bounds__(256, 2) void syrk_kernel(T* __restrict__ A, long ld, int k, int jbeg) {
   using G = TileGemm<T, true, true>;
   __shared__ T smem[G::SMEM_ELEMS];
   int bi, bj;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) void syrk_kernel(T* __restrict__ A, long ld, i
 
 // the lookahead column: only block column jcol, 64x64 tiles (latency-critical, see trsm_kernel)
 template <typename T>
-__global__ __launch_bounds__(256) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int jcol) {
+__global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int jcol) {
   using G = TileGemm<T, true, true, 64, 64>;
   __shared__ T smem[G::SMEM_ELEMS];
   const long row0 = (long)jcol * NB + (long)blockIdx.x * 64;
@@ -281,7 +285,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
   auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
   if (!lookahead || nbk < 3 || s2 == nullptr || ev == nullptr) {
     for (int k = 0; k < nbk; ++k) {
-      potrf_diag_kernel<T><<<1, 256, 0, s>>>(A, N, (long)k * NB, Tinv, logdet, info);
+      potrf_diag_kernel<T, NB><<<1, 256, 0, s>>>(A, N, (long)k * NB, Tinv, logdet, info);
       if (k + 1 < nbk) {
         trsm_kernel<T><<<2 * (nbk - k - 1), 256, 0, s>>>(A, Tinv, N, k);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
@@ -296,7 +300,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
   // one-panel lookahead: stream s carries the panel chain, s2 the bulk trailing updates.
   hipEvent_t* P = ev;        // P[k]: panel k (diag + trsm) ready
   hipEvent_t* U = ev + nbk;  // U[k]: bulk update with panel k done
-  potrf_diag_kernel<T><<<1, 256, 0, s>>>(A, N, 0, Tinv, logdet, info);
+  potrf_diag_kernel<T, NB><<<1, 256, 0, s>>>(A, N, 0, Tinv, logdet, info);
   trsm_kernel<T><<<2 * (nbk - 1), 256, 0, s>>>(A, Tinv, N, 0);
   hipEventRecord(P[0], s);
   int last_u = -1;
@@ -312,7 +316,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     }
     if (k >= 1) hipStreamWaitEvent(s, U[k - 1], 0);
     syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k, k + 1);
-    potrf_diag_kernel<T><<<1, 256, 0, s>>>(A, N, (long)(k + 1) * NB, Tinv, logdet, info);
+    potrf_diag_kernel<T, NB><<<1, 256, 0, s>>>(A, N, (long)(k + 1) * NB, Tinv, logdet, info);
     if (k + 2 < nbk) {
       trsm_kernel<T><<<2 * (nbk - k - 2), 256, 0, s>>>(A, Tinv, N, k + 1);
       hipEventRecord(P[k + 1], s);
@@ -328,7 +332,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
 //   W[i,j] = sum_{c=j}^{mid-1} L[i,c] T[c,j]      (i in [mid,hi), j in [lo,mid))
 //   T[i,j] = - sum_{c=mid}^{i} T[i,c] W[c,j]
 template <typename T, int STEP>
-__global__ __launch_bounds__(256) void trtri_level_kernel(const T* __restrict__ L, T* __restrict__ Tm,
+__global__ __launch_bounds__(256, 2) void trtri_level_kernel(const T* __restrict__ L, T* __restrict__ Tm,
                                                           T* __restrict__ W, long ld, int m, int nbk) {
   using G = TileGemm<T, true, false>;
   __shared__ T smem[G::SMEM_ELEMS];
@@ -367,7 +371,7 @@ int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long
 // ------------------------------------------------------------------------------------------
 // S[i,j] = sum_{c >= i} T[c,i]^T T[c,j]   (i >= j): K^^-1 = L^-T L^-1
 template <typename T>
-__global__ __launch_bounds__(256) void lauum_kernel(const T* __restrict__ Tm, T* __restrict__ S, long ld, int nbk) {
+__global__ __launch_bounds__(256, 2) void lauum_kernel(const T* __restrict__ Tm, T* __restrict__ S, long ld, int nbk) {
   using G = TileGemm<T, false, false>;
   __shared__ T smem[G::SMEM_ELEMS];
   int bi, bj;
@@ -475,7 +479,7 @@ int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s) 
 // prediction: V = T Ks (N x M, Ks = K(X, X*) padded to M % 128 == 0), var_j = kss_j - sum_i V_ij^2,
 // mean_j = sum_i Ks_ij alpha_i      (src/discontinuum/engines/gpytorch.py:621-624)
 template <typename T>
-__global__ __launch_bounds__(256) void predict_v_kernel(const T* __restrict__ Tm, long N, const T* __restrict__ Ks,
+__global__ __launch_bounds__(256, 2) void predict_v_kernel(const T* __restrict__ Tm, long N, const T* __restrict__ Ks,
                                                         long M, T* __restrict__ V) {
   using G = TileGemm<T, true, false>;
   __shared__ T smem[G::SMEM_ELEMS];
@@ -521,7 +525,7 @@ int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, 
 
 // cov[i,j] = Kss[i,j] - sum_k V[k,i] V[k,j]  (i >= j tiles), k over all N rows of V (N x M)
 template <typename T>
-__global__ __launch_bounds__(256) void posterior_cov_kernel(const T* __restrict__ V, long N, long M, T* __restrict__ cov) {
+__global__ __launch_bounds__(256, 2) void posterior_cov_kernel(const T* __restrict__ V, long N, long M, T* __restrict__ cov) {
   using G = TileGemm<T, false, false>;
   __shared__ T smem[G::SMEM_ELEMS];
   int bi, bj;

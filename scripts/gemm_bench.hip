@@ -41,7 +41,47 @@ int bench(const char* name, long n, int K) {
   return 0;
 }
 
+// syrk-like: lower-triangular tile grid, C -= A_i A_j^T with K = ktiles*16 (panel at column offset 0)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void syrk_like(T* A, long n, int ktiles, int jbeg) {
+  using G = TileGemm<T, true, true>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  int bi, bj;
+  tri_decode(blockIdx.x, bi, bj);
+  bi += jbeg; bj += jbeg;
+  typename G::acc_t acc[G::MI][G::NI];
+  T* C = A + (long)bi * 128 * n + (long)bj * 128;
+  if (MODE == 0) G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * n + c]; });
+  else G::zero(acc);
+  G::run(A + (long)bi * 128 * n, n, A + (long)bj * 128 * n, n, ktiles, smem, acc);
+  if (MODE == 0) G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * n + c] = -v; });
+  else G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * n + c] = v; });
+}
+template <typename T, int MODE>
+int bench_syrk(const char* name, long n, int K) {
+  T* A; CK(hipMalloc(&A, n * n * sizeof(T)));
+  CK(hipMemset(A, 0, n * n * sizeof(T)));
+  const int jbeg = K / 128, m = (int)(n / 128) - jbeg;
+  const unsigned grid = m * (m + 1) / 2;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  syrk_like<T, MODE><<<grid, 256>>>(A, n, K / 16, jbeg); CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) syrk_like<T, MODE><<<grid, 256>>>(A, n, K / 16, jbeg);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+  printf("%-28s n=%ld K=%d tiles=%u: %.3f ms  %.1f TFLOP/s\n", name, n, K, grid, ms, 2.0 * grid * 128.0 * 128.0 * K / ms / 1e9);
+  CK(hipFree(A));
+  return 0;
+}
+
 int main() {
+  bench_syrk<double, 0>("f64 syrk RMW K=128", 8192, 128);
+  bench_syrk<double, 1>("f64 syrk store-only K=128", 8192, 128);
+  bench_syrk<double, 0>("f64 syrk RMW K=256", 8192, 256);
+  bench_syrk<double, 0>("f64 syrk RMW K=512", 8192, 512);
+  bench_syrk<double, 0>("f64 syrk RMW K=128 n=4096", 4096, 128);
+
   const long n = 8192;
   bench<double, true, true, 128, 128>("f64 KC/KC", n, 8192);
   bench<double, true, false, 128, 128>("f64 KC/IC", n, 8192);
