@@ -12,6 +12,7 @@
 //   lauum   S = T^T T = K^^-1, one launch, triangular k-range per tile
 //   solve   z = T r, quad = z^T z, alpha = T^T z (bandwidth-bound, deterministic two-stage sums)
 // Flops per fit: N^3/3 (potrf) + N^3/3 (trtri) + N^3/3 (lauum) -- MFMA roofline.
+#include "dgp_diag.h"
 #include "dgp_gemm.h"
 #include "dgp_internal.h"
 
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T
   // 64 rows x all 128 panel columns per workgroup: a workgroup only ever reads the rows it overwrites
   using G = TileGemm<T, true, true, 64, 128>;
   __shared__ T smem[G::SMEM_ELEMS];
+  __builtin_amdgcn_s_setprio(3);  // panel chain: outrank co-resident bulk-update waves
   const long row0 = (long)(k + 1) * NB + (long)blockIdx.x * 64;
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
@@ -260,6 +262,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int jcol) {
   using G = TileGemm<T, true, true, 64, 64>;
   __shared__ T smem[G::SMEM_ELEMS];
+  __builtin_amdgcn_s_setprio(3);  // panel chain: outrank co-resident bulk-update waves
   const long row0 = (long)jcol * NB + (long)blockIdx.x * 64;
   const long col0 = (long)jcol * NB + (long)blockIdx.y * 64;
   if (col0 > row0 + 63) return;  // strictly upper 64x64 quadrant of the diagonal block
@@ -276,6 +279,19 @@ __global__ void zero1_kernel(T* p, int* info) {
   info[0] = 0;
 }
 
+// launch the LDS-resident diagonal-block kernel (needs > 64 KB of dynamic LDS: opt in once per type)
+template <typename T>
+static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hipStream_t s) {
+  static bool configured = false;
+  const size_t bytes = potrf_diag_fast_smem<T>();
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_fast_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    configured = true;
+  }
+  potrf_diag_fast_kernel<T><<<1, 256, bytes, s>>>(A, N, k0, Tinv, logdet, info);
+}
+
 template <typename T>
 int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
           hipEvent_t* syrk_ev, int* n_syrk) {
@@ -285,7 +301,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
   auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
   if (!lookahead || nbk < 3 || s2 == nullptr || ev == nullptr) {
     for (int k = 0; k < nbk; ++k) {
-      potrf_diag_kernel<T, NB><<<1, 256, 0, s>>>(A, N, (long)k * NB, Tinv, logdet, info);
+      launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s);
       if (k + 1 < nbk) {
         trsm_kernel<T><<<2 * (nbk - k - 1), 256, 0, s>>>(A, Tinv, N, k);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
@@ -300,7 +316,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
   // one-panel lookahead: stream s carries the panel chain, s2 the bulk trailing updates.
   hipEvent_t* P = ev;        // P[k]: panel k (diag + trsm) ready
   hipEvent_t* U = ev + nbk;  // U[k]: bulk update with panel k done
-  potrf_diag_kernel<T, NB><<<1, 256, 0, s>>>(A, N, 0, Tinv, logdet, info);
+  launch_diag<T>(A, N, 0, Tinv, logdet, info, s);
   trsm_kernel<T><<<2 * (nbk - 1), 256, 0, s>>>(A, Tinv, N, 0);
   hipEventRecord(P[0], s);
   int last_u = -1;
@@ -316,7 +332,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     }
     if (k >= 1) hipStreamWaitEvent(s, U[k - 1], 0);
     syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k, k + 1);
-    potrf_diag_kernel<T, NB><<<1, 256, 0, s>>>(A, N, (long)(k + 1) * NB, Tinv, logdet, info);
+    launch_diag<T>(A, N, (long)(k + 1) * NB, Tinv, logdet, info, s);
     if (k + 2 < nbk) {
       trsm_kernel<T><<<2 * (nbk - k - 2), 256, 0, s>>>(A, Tinv, N, k + 1);
       hipEventRecord(P[k + 1], s);

@@ -1,0 +1,53 @@
+"""Independent sites across the GPUs of one node (BASELINE config 4).
+
+The reference's only parallelism is "one site = one fit" mapped over AWS Lambda
+(``examples/nwqn-loadest-example/nwqn-loadest-example.py:156-159``).  Here one process drives one GPU;
+site i belongs to rank i mod G, every rank runs its sites through its own device plan, and the only
+communication is one ``all_gather`` of the per-site result rows (NLL, info, gradients) -- RCCL over xGMI
+when the tensors live on GPUs, gloo for the CPU tests.  There is no data-path collective.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def site_partition(n_sites: int, world: int, rank: int) -> list[int]:
+    """Sites owned by ``rank``: round-robin, so a sweep of equally sized sites is balanced."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return list(range(rank, n_sites, world))
+
+
+def gather_site_results(local: torch.Tensor, n_sites: int, group=None) -> torch.Tensor:
+    """All ranks contribute ``local`` (rows = their sites in ``site_partition`` order, R columns) and
+    receive the full ``(n_sites, R)`` table in site order.  Ragged shares are padded for the collective."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if local.shape[0] != n_sites:
+            raise ValueError("single-process gather needs all sites locally")
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (n_sites + world - 1) // world
+    mine = site_partition(n_sites, world, rank)
+    if local.shape[0] != len(mine):
+        raise ValueError(f"rank {rank} owns {len(mine)} sites but passed {local.shape[0]} rows")
+    pad = torch.zeros(per, local.shape[1], dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.empty(n_sites, local.shape[1], dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = site_partition(n_sites, world, r)
+        out[idx] = parts[r][: len(idx)]
+    return out
+
+
+def fit_sites(plan, Xs, rs, noises, theta):
+    """One fit step for each local site (all sites share (model, n, d), so one plan / workspace is reused):
+    returns the stacked ``(B_local, OUT_LEN)`` result rows on the plan's device."""
+    rows = []
+    for X, r, noise in zip(Xs, rs, noises):
+        plan.set_inputs(X)
+        out, _dr, _dn = plan.fit_step(theta, r, noise)
+        rows.append(out)
+    return torch.stack(rows) if rows else torch.empty(0, 32, dtype=plan.dtype, device=plan.device)

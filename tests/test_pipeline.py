@@ -1,0 +1,54 @@
+"""Data layer: the reference's own known answer and round trips."""
+import numpy as np
+
+from discontinuum_amd.data_manager import DataManager
+from discontinuum_amd.pipeline import (
+    LogErrorPipeline,
+    LogStandardPipeline,
+    TimePipeline,
+    TimeTransformer,
+    UnitPipeline,
+)
+from discontinuum_amd.xr_compat import DataArray, Dataset
+
+
+def test_time_transformer_known_answer():
+    """Values pinned by the reference: src/discontinuum/tests/test_pipeline.py:14."""
+    t = np.array(["2022-01-01", "2022-02-01", "2022-03-01"], dtype="datetime64[ns]")
+    tt = TimeTransformer()
+    out = tt.transform(t)
+    assert np.allclose(out, [2022.0, 2022.08493151, 2022.16164384], atol=1e-6)
+    assert np.all(tt.inverse_transform(out) == t)
+
+
+def test_log_error_pipeline_shape():
+    x = DataArray(np.abs(np.random.default_rng(0).standard_normal(10)) + 0.1, dims=("time",), name="c")
+    assert LogErrorPipeline().fit(x).transform(x).shape == (10, 1)
+
+
+def test_pipelines_round_trip_and_ranges():
+    rng = np.random.default_rng(1)
+    x = DataArray(np.exp(rng.standard_normal(50)), dims=("time",), name="q", attrs={"units": "cfs"})
+    p = LogStandardPipeline().fit(x)
+    z = p.transform(x)
+    assert abs(z.mean()) < 1e-12 and abs(z.std() - 1) < 1e-12
+    back = p.inverse_transform(z)
+    assert np.allclose(back.values, x.values) and back.attrs == {"units": "cfs"} and back.name == "q"
+    u = UnitPipeline().fit(x).transform(x)
+    assert np.isclose(u.min(), 1.0) and np.isclose(u.max(), 2.0)  # stage scaled to [1, 2]
+    lo, hi = LogErrorPipeline().ci(np.array([10.0]), np.array([1.2]))
+    assert lo < 10 < hi and np.isclose(lo * hi, 100.0)
+
+
+def test_data_manager_design_matrix():
+    t = np.arange("2015-01-01", "2015-03-01", dtype="datetime64[D]").astype("datetime64[ns]")
+    flow = np.linspace(1, 50, t.size)
+    cov = Dataset({"flow": ("time", flow)}, coords={"time": t})
+    tgt = DataArray(np.sqrt(flow), dims=("time",), coords={"time": t}, name="c")
+    dm = DataManager(covariate_pipelines={"time": TimePipeline, "flow": LogStandardPipeline})
+    dm.fit(target=tgt, covariates=cov)
+    assert dm.X.shape == (t.size, 2) and dm.y.shape == (t.size,)
+    assert abs(dm.X[:, 0].mean()) < 1e-9  # time is centred, not scaled
+    assert dm.get_dim("time") == 0 and dm.get_dim("flow") == 1
+    assert np.allclose(dm.y_t(dm.y).values, tgt.values)
+    assert np.allclose(dm.Xnew(cov), dm.X)
