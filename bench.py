@@ -55,7 +55,7 @@ def syrk_flops(N, lookahead=True):
     return tiles * 2.0 * 128 ** 3, launches
 
 
-def cpu_baseline(n, d, dtype_name, budget_s=45.0):
+def cpu_baseline(n, d, dtype_name, budget_s=75.0):
     """Time the oracle's NLL + gradient step on the host.  Probe at n=2048, then run the largest
     n <= target whose cubic extrapolation fits the budget."""
     from oracle import gp_oracle as orc
