@@ -344,42 +344,53 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------
-// trtri level of half-size m blocks: group g covers block rows/cols [lo, hi), split at mid.
+// trtri level with half-size m (in tiles of BT rows): group g covers tile rows/cols [lo, hi), split at mid.
 //   W[i,j] = sum_{c=j}^{mid-1} L[i,c] T[c,j]      (i in [mid,hi), j in [lo,mid))
 //   T[i,j] = - sum_{c=mid}^{i} T[i,c] W[c,j]
-template <typename T, int STEP>
+// BT = 128 for the large levels; the small levels (few tiles, short k) use 64x64 tiles so that four
+// times as many workgroups share the work.
+template <typename T, int STEP, int BT>
 __global__ __launch_bounds__(256, 2) void trtri_level_kernel(const T* __restrict__ L, T* __restrict__ Tm,
-                                                          T* __restrict__ W, long ld, int m, int nbk) {
-  using G = TileGemm<T, true, false>;
+                                                             T* __restrict__ W, long ld, int m, int ntile) {
+  using G = TileGemm<T, true, false, BT, BT>;
   __shared__ T smem[G::SMEM_ELEMS];
-  const int lo = 2 * m * blockIdx.y, mid = lo + m, hi = min(lo + 2 * m, nbk);
+  const int lo = 2 * m * blockIdx.y, mid = lo + m, hi = min(lo + 2 * m, ntile);
   // longest k-range first: W-step K ~ (mid - j), T-step K ~ (i - mid + 1)
   const int i = STEP == 0 ? mid + blockIdx.x % m : mid + (m - 1 - blockIdx.x / m);
   const int j = STEP == 0 ? lo + blockIdx.x / m : lo + blockIdx.x % m;
   if (i >= hi) return;
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
+  constexpr int KT = BT / 16;  // k-tiles per tile of the reduction dimension
   if (STEP == 0) {
-    G::run(L + (long)i * NB * ld + (long)j * NB, ld, Tm + (long)j * NB * ld + (long)j * NB, ld, (mid - j) * (NB / 16),
-           smem, acc);
-    T* out = W + (long)i * NB * ld + (long)j * NB;
+    G::run(L + (long)i * BT * ld + (long)j * BT, ld, Tm + (long)j * BT * ld + (long)j * BT, ld, (mid - j) * KT, smem,
+           acc);
+    T* out = W + (long)i * BT * ld + (long)j * BT;
     G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
   } else {
-    G::run(Tm + (long)i * NB * ld + (long)mid * NB, ld, W + (long)mid * NB * ld + (long)j * NB, ld,
-           (i - mid + 1) * (NB / 16), smem, acc);
-    T* out = Tm + (long)i * NB * ld + (long)j * NB;
+    G::run(Tm + (long)i * BT * ld + (long)mid * BT, ld, W + (long)mid * BT * ld + (long)j * BT, ld, (i - mid + 1) * KT,
+           smem, acc);
+    T* out = Tm + (long)i * BT * ld + (long)j * BT;
     G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = -v; });
   }
+}
+
+template <typename T, int BT>
+static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, hipStream_t s) {
+  const int per = NB / BT;                   // tiles per 128-block
+  const int m = mblk * per, ntile = (int)(N / BT);
+  const int ngroups = (ntile + 2 * m - 1) / (2 * m);
+  dim3 grid((unsigned)(m * m), (unsigned)ngroups);
+  trtri_level_kernel<T, 0, BT><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile);
+  trtri_level_kernel<T, 1, BT><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile);
 }
 
 template <typename T>
 int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long N, T* Tm, T* W, hipStream_t s) {
   const int nbk = (int)(N / NB);
   for (int m = 1; m < nbk; m *= 2) {
-    const int ngroups = (nbk + 2 * m - 1) / (2 * m);
-    dim3 grid((unsigned)(m * m), (unsigned)ngroups);
-    trtri_level_kernel<T, 0><<<grid, 256, 0, s>>>(L, Tm, W, N, m, nbk);
-    trtri_level_kernel<T, 1><<<grid, 256, 0, s>>>(L, Tm, W, N, m, nbk);
+    if (m <= 8) trtri_level<T, 64>(L, Tm, W, N, m, s);
+    else trtri_level<T, 128>(L, Tm, W, N, m, s);
   }
   return (int)hipGetLastError();
 }

@@ -122,6 +122,21 @@ __device__ __forceinline__ T frag_cr(const T* blk, int ks, int lane) {  // eleme
   return blk[(4 * ks + (lane >> 4)) * DGP_DS + (lane & 15)];
 }
 
+// An accumulator block (C layout) can feed the next MFMA as its B operand without moving data:
+//   fp64: C row = (lane>>4) + 4r  == B row of k-step r            -> natural k order
+//   fp32: C row = 4(lane>>4) + r  == B row 4q + r of lane group q -> the A operand must then present
+//         column 4q + r in "k-step" r (a consistent permutation of the summation index)
+template <typename T>
+__device__ __forceinline__ T frag_rc_acc(const T* blk, int r, int lane);
+template <>
+__device__ __forceinline__ double frag_rc_acc<double>(const double* blk, int r, int lane) {
+  return blk[(lane & 15) * DGP_DS + 4 * r + (lane >> 4)];
+}
+template <>
+__device__ __forceinline__ float frag_rc_acc<float>(const float* blk, int r, int lane) {
+  return blk[(lane & 15) * DGP_DS + 4 * (lane >> 4) + r];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A, long ld, long k0,
                                                               T* __restrict__ Tinv, T* __restrict__ logdet,
@@ -191,64 +206,56 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
     __syncthreads();
   }
 
-  // ---- L is final: stream it to global (zeros above the block diagonal).  The inverse below reads
-  // its L operands back from L2, which frees the LDS copy to receive the off-diagonal blocks of L^-1.
+  // ---- L is final: stream it to global (zeros above the block diagonal); nothing waits for these stores
 #pragma unroll
   for (int bi = 0; bi < DGP_DNB; ++bi)
 #pragma unroll
     for (int bj = 0; bj < DGP_DNB; ++bj)
       Ablk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = bj <= bi ? sL[dtri(bi, bj) * DGP_DBLK + ti * DGP_DS + tj] : T(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have left this CU ...
-  __syncthreads();                                   // ... for every wave, before anyone reads them back
 
-  // ---- L^-1 by block forward substitution: wave w owns block columns w and 7 - w
-  const int fr = lane & 15, fq = lane >> 4;
+  // ---- L^-1 by block forward substitution: wave w owns block columns w and 7 - w.  The finished blocks
+  // X_cj of the column stay in REGISTERS (accumulator layout == B-operand layout, see frag_rc_acc), so
+  // this phase touches LDS only for its A operands (L_ic, Linv_ii) and global memory only for stores.
+  const int crow0 = Mfma<T>::crow(lane, 0);
   for (int half = 0; half < 2; ++half) {
     const int j = half == 0 ? wave : DGP_DNB - 1 - wave;
-    for (int i = j + 1; i < DGP_DNB; ++i) {
-      // all L fragments of block row i, columns j..i-1, in flight at once (L1-bypassing loads: this
-      // CU's L1 may still hold the pre-factorisation lines of the block)
-      T lf[DGP_DNB - 1][4];
+    const T* Xjj = sXd + j * DGP_DBLK;
+    acc_t xb[DGP_DNB - 1];  // xb[d - 1] = X_{j+d, j}
 #pragma unroll
-      for (int cc = 0; cc < DGP_DNB - 1; ++cc)
+    for (int di = 1; di < DGP_DNB; ++di) {
+      const int i = j + di;
+      if (i < DGP_DNB) {
+        acc_t acc = {T(0), T(0), T(0), T(0)};
+        {  // c = j: X_jj comes from LDS in natural k order
+          const T* Lij = sL + dtri(i, j) * DGP_DBLK;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int c = j + cc;
-          lf[cc][ks] = c < i ? __builtin_nontemporal_load(&Ablk[(long)(16 * i + fr) * ld + 16 * c + 4 * ks + fq]) : T(0);
+          for (int ks = 0; ks < 4; ++ks) acc = Mfma<T>::mma(frag_rc(Lij, ks, lane), frag_cr(Xjj, ks, lane), acc);
         }
-      acc_t acc = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-      for (int cc = 0; cc < DGP_DNB - 1; ++cc) {
-        const int c = j + cc;
-        if (c < i) {
-          const T* Xcj = (c == j) ? sXd + j * DGP_DBLK : sL + dtri(c, j) * DGP_DBLK;
+        for (int dc = 1; dc < di; ++dc) {  // c = j + dc: X_cj is a register block
+          const T* Lic = sL + dtri(i, j + dc) * DGP_DBLK;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) acc = Mfma<T>::mma(lf[cc][ks], frag_cr(Xcj, ks, lane), acc);
+          for (int r = 0; r < 4; ++r) acc = Mfma<T>::mma(frag_rc_acc<T>(Lic, r, lane), xb[dc - 1][r], acc);
         }
+        const T* Xii = sXd + i * DGP_DBLK;
+        acc_t out = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out = Mfma<T>::mma(-frag_rc_acc<T>(Xii, r, lane), acc[r], out);
+        xb[di - 1] = out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Xblk[(long)(16 * i + Mfma<T>::crow(lane, r)) * ld + 16 * j + (lane & 15)] = out[r];
       }
-      // X_ij = -Linv_ii * W : park W in the destination sub-block, read it back as the B operand
-      T* Xij = sL + dtri(i, j) * DGP_DBLK;
-      const T* Xii = sXd + i * DGP_DBLK;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Xij[Mfma<T>::crow(lane, r) * DGP_DS + (lane & 15)] = acc[r];
-      acc_t out = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) out = Mfma<T>::mma(-frag_rc(Xii, ks, lane), frag_cr(Xij, ks, lane), out);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Xij[Mfma<T>::crow(lane, r) * DGP_DS + (lane & 15)] = out[r];
     }
   }
-  __syncthreads();
+  (void)crow0;
 
-  // ---- L^-1 into the diagonal block of Tinv (zeros above the block diagonal)
+  // ---- diagonal sub-blocks of L^-1 and the zeros above the block diagonal
 #pragma unroll
   for (int bi = 0; bi < DGP_DNB; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < DGP_DNB; ++bj) {
-      const int o = ti * DGP_DS + tj;
-      const T v = bj < bi ? sL[dtri(bi, bj) * DGP_DBLK + o] : (bj == bi ? sXd[bi * DGP_DBLK + o] : T(0));
-      Xblk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = v;
-    }
+    for (int bj = bi; bj < DGP_DNB; ++bj)
+      Xblk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = bj == bi ? sXd[bi * DGP_DBLK + ti * DGP_DS + tj] : T(0);
   // ---- log-determinant and first bad pivot (fixed-order tree: reproducible)
   __shared__ T red[128];
   __shared__ int bad;
