@@ -170,10 +170,24 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
   }
   __syncthreads();
 
-  // ---- blocked right-looking Cholesky on the sub-blocks
-  for (int kb = 0; kb < DGP_DNB; ++kb) {
-    if (wave == 0) gj16<T>(sL + dtri(kb, kb) * DGP_DBLK, sXd + kb * DGP_DBLK, dvals + 16 * kb, lane);
-    __syncthreads();
+  // ---- blocked right-looking Cholesky on the sub-blocks, software-pipelined: while wave 0 runs the
+  // sequential 16-pivot sweep of the NEXT diagonal sub-block (which only needs that one sub-block
+  // updated), waves 1-3 apply the rest of the current trailing update.
+  auto update_block = [&](int bi, int bj, int kb) {  // A_ij -= L_ik L_jk^T
+    T* C = sL + dtri(bi, bj) * DGP_DBLK;
+    const T* Li = sL + dtri(bi, kb) * DGP_DBLK;
+    const T* Lj = sL + dtri(bj, kb) * DGP_DBLK;
+    acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = C[Mfma<T>::crow(lane, r) * DGP_DS + (lane & 15)];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = Mfma<T>::mma(-frag_rc(Li, ks, lane), frag_rc(Lj, ks, lane), acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[Mfma<T>::crow(lane, r) * DGP_DS + (lane & 15)] = acc[r];
+  };
+  if (wave == 0) gj16<T>(sL + dtri(0, 0) * DGP_DBLK, sXd, dvals, lane);
+  __syncthreads();
+  for (int kb = 0; kb < DGP_DNB - 1; ++kb) {
     // panel: L_ik = A_ik * Linv_kk^T
     const T* Xkk = sXd + kb * DGP_DBLK;
     for (int i = kb + 1 + wave; i < DGP_DNB; i += 4) {
@@ -185,23 +199,17 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
       for (int r = 0; r < 4; ++r) blk[Mfma<T>::crow(lane, r) * DGP_DS + (lane & 15)] = acc[r];
     }
     __syncthreads();
-    // trailing update: A_ij -= L_ik L_jk^T for kb < j <= i
-    const int m = DGP_DNB - 1 - kb;
-    for (int idx = wave; idx < m * (m + 1) / 2; idx += 4) {
-      int bi, bj;
-      tri_decode(idx, bi, bj);
-      bi += kb + 1;
-      bj += kb + 1;
-      T* C = sL + dtri(bi, bj) * DGP_DBLK;
-      const T* Li = sL + dtri(bi, kb) * DGP_DBLK;
-      const T* Lj = sL + dtri(bj, kb) * DGP_DBLK;
-      acc_t acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = C[Mfma<T>::crow(lane, r) * DGP_DS + (lane & 15)];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc = Mfma<T>::mma(-frag_rc(Li, ks, lane), frag_rc(Lj, ks, lane), acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) C[Mfma<T>::crow(lane, r) * DGP_DS + (lane & 15)] = acc[r];
+    // trailing update A_ij -= L_ik L_jk^T (kb < j <= i), next pivot block first
+    const int m = DGP_DNB - 1 - kb, nblk = m * (m + 1) / 2;
+    if (wave == 0) {
+      update_block(kb + 1, kb + 1, kb);
+      gj16<T>(sL + dtri(kb + 1, kb + 1) * DGP_DBLK, sXd + (kb + 1) * DGP_DBLK, dvals + 16 * (kb + 1), lane);
+    } else {
+      for (int idx = wave; idx < nblk; idx += 3) {  // idx 0 is the pivot block handled by wave 0
+        int bi, bj;
+        tri_decode(idx, bi, bj);
+        update_block(bi + kb + 1, bj + kb + 1, kb);
+      }
     }
     __syncthreads();
   }
