@@ -34,6 +34,7 @@ struct dgp_plan {
   int nev;
   // optional HIP-event timing of the fit-step stages
   int timing, n_syrk, timed_valid;
+  double syrk_flop;
   hipEvent_t* tev;   // 2 per stage (start, stop)
   hipEvent_t* sev;   // 2 per bulk syrk launch
   int nsev;
@@ -227,7 +228,7 @@ static int run_potrf(dgp_plan* p, hipStream_t s) {
   if (rc) return rc;
   if ((rc = ensure_timing(p))) return rc;
   return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, p->lookahead, s, p->s2, p->ev,
-                  p->timing ? p->sev : nullptr, &p->n_syrk);
+                  p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop);
 }
 template <typename T>
 static int run_trtri(dgp_plan* p, hipStream_t s) {
@@ -440,6 +441,7 @@ int dgp_plan_get_timing(dgp_plan* p, double* ms_out) {
   }
   ms_out[DGP_TIME_SYRK_SUM] = sum;
   ms_out[DGP_TIME_SYRK_N] = p->n_syrk;
+  ms_out[DGP_TIME_SYRK_FLOP] = p->syrk_flop;
   return 0;
 }
 

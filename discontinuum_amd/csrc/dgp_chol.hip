@@ -239,11 +239,12 @@ __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T
   G::foreach (acc, [&](int r, int c, T& v) { Arow[(long)r * ld + c] = v; });
 }
 
-// A[i,j] -= A[i,k] A[j,k]^T for the lower tiles with block column >= jbeg (bulk trailing update).
+// A[i,j] -= sum over panels k..k+nk-1 of A[i,p] A[j,p]^T for the lower tiles with block column >= jbeg
+// (bulk trailing update; nk = 2 halves the passes over the trailing matrix: 53.6 vs 44.5 TFLOP/s in isolation).
 // The accumulators start at -C, so the read of C overlaps the first operand loads and the epilogue
 // is store-only:  C_new = -( -C + P_i P_j^T ).
 template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_kernel(T* __restrict__ A, long ld, int k, int jbeg) {
+__global__ __launch_bounds__(256, 2) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg) {
   using G = TileGemm<T, true, true>;
   __shared__ T smem[G::SMEM_ELEMS];
   int bi, bj;
@@ -253,13 +254,14 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(T* __restrict__ A, long ld
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + (long)bi * NB * ld + (long)bj * NB;
   G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * ld + c]; });
-  G::run(A + (long)bi * NB * ld + (long)k * NB, ld, A + (long)bj * NB * ld + (long)k * NB, ld, NB / 16, smem, acc);
+  G::run(A + (long)bi * NB * ld + (long)k * NB, ld, A + (long)bj * NB * ld + (long)k * NB, ld, nk * (NB / 16), smem,
+         acc);
   G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] = -v; });
 }
 
 // the lookahead column: only block column jcol, 64x64 tiles (latency-critical, see trsm_kernel)
 template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int jcol) {
+__global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int nk, int jcol) {
   using G = TileGemm<T, true, true, 64, 64>;
   __shared__ T smem[G::SMEM_ELEMS];
   __builtin_amdgcn_s_setprio(3);  // panel chain: outrank co-resident bulk-update waves
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, lon
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
   G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * ld + c]; });
-  G::run(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, NB / 16, smem, acc);
+  G::run(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc);
   G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] = -v; });
 }
 
@@ -294,52 +296,74 @@ static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hi
 
 template <typename T>
 int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
-          hipEvent_t* syrk_ev, int* n_syrk) {
-  int ns = 0;
+          hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop) {
   const int nbk = (int)(N / NB);
+  int ns = 0;
+  double flop = 0.0;
   zero1_kernel<T><<<1, 1, 0, s>>>(logdet, info);
   auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
-  if (!lookahead || nbk < 3 || s2 == nullptr || ev == nullptr) {
+  const double tile_flop = 2.0 * NB * NB * NB;
+  if (!lookahead || nbk < 4 || s2 == nullptr || ev == nullptr) {
     for (int k = 0; k < nbk; ++k) {
       launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s);
       if (k + 1 < nbk) {
         trsm_kernel<T><<<2 * (nbk - k - 1), 256, 0, s>>>(A, Tinv, N, k);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
-        syrk_kernel<T><<<tri(nbk - k - 1), 256, 0, s>>>(A, N, k, k + 1);
+        syrk_kernel<T><<<tri(nbk - k - 1), 256, 0, s>>>(A, N, k, 1, k + 1);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s);
+        flop += tile_flop * tri(nbk - k - 1);
         ++ns;
       }
     }
     if (n_syrk) *n_syrk = ns;
+    if (syrk_flop) *syrk_flop = flop;
     return (int)hipGetLastError();
   }
-  // one-panel lookahead: stream s carries the panel chain, s2 the bulk trailing updates.
-  hipEvent_t* P = ev;        // P[k]: panel k (diag + trsm) ready
-  hipEvent_t* U = ev + nbk;  // U[k]: bulk update with panel k done
+  // One-panel lookahead with PAIRED bulk updates.  Stream s carries the panel chain
+  //     column update (k -> k+1)  ->  diag(k+1)  ->  trsm(k+1)
+  // and stream s2 (lowest priority) the bulk trailing update, launched once per two panels with
+  // K = 256:   after panel k = 2p+1 is ready, panels (2p, 2p+1) update block columns >= 2p+3.
+  // Column 2p+1 gets panel 2p, and column 2p+2 gets panels (2p, 2p+1), from the chain itself.
+  //   P[k]: panel k ready (recorded for odd k)      U[p]: bulk update of pair p done
+  hipEvent_t* P = ev;
+  hipEvent_t* U = ev + nbk;
   launch_diag<T>(A, N, 0, Tinv, logdet, info, s);
   trsm_kernel<T><<<2 * (nbk - 1), 256, 0, s>>>(A, Tinv, N, 0);
-  hipEventRecord(P[0], s);
   int last_u = -1;
   for (int k = 0; k + 1 < nbk; ++k) {
-    if (k + 2 < nbk) {
+    const bool odd = (k & 1) != 0;
+    const int p = k >> 1;
+    if (odd && k + 2 < nbk) {
       hipStreamWaitEvent(s2, P[k], 0);
       if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
-      syrk_kernel<T><<<tri(nbk - k - 2), 256, 0, s2>>>(A, N, k, k + 2);
+      syrk_kernel<T><<<tri(nbk - k - 2), 256, 0, s2>>>(A, N, k - 1, 2, k + 2);
       if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
+      flop += 2.0 * tile_flop * tri(nbk - k - 2);
       ++ns;
-      hipEventRecord(U[k], s2);
-      last_u = k;
+      hipEventRecord(U[p], s2);
     }
-    if (k >= 1) hipStreamWaitEvent(s, U[k - 1], 0);
-    syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k, k + 1);
+    // column k+1 must carry every earlier pair before the chain adds its own panels: pair p-1 is the last
+    // bulk launch that touches it (pair p starts at column 2p+3 > k+1)
+    if (p >= 1 && last_u < p - 1) {
+      hipStreamWaitEvent(s, U[p - 1], 0);
+      last_u = p - 1;
+    }
+    if (odd) syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k - 1, 2, k + 1);
+    else syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k, 1, k + 1);
     launch_diag<T>(A, N, (long)(k + 1) * NB, Tinv, logdet, info, s);
     if (k + 2 < nbk) {
       trsm_kernel<T><<<2 * (nbk - k - 2), 256, 0, s>>>(A, Tinv, N, k + 1);
-      hipEventRecord(P[k + 1], s);
+      if (((k + 1) & 1) != 0 && k + 3 < nbk) hipEventRecord(P[k + 1], s);
     }
   }
-  if (last_u >= 0) hipStreamWaitEvent(s, U[last_u], 0);
+  // join: the last bulk launch must precede whatever the caller enqueues next on s
+  {
+    const int kmax = ((nbk - 3) & 1) ? nbk - 3 : nbk - 4;  // largest odd k with k + 2 < nbk
+    const int last_pair = kmax >= 1 ? (kmax - 1) / 2 : -1;
+    if (last_pair >= 0 && last_u < last_pair) hipStreamWaitEvent(s, U[last_pair], 0);
+  }
   if (n_syrk) *n_syrk = ns;
+  if (syrk_flop) *syrk_flop = flop;
   return (int)hipGetLastError();
 }
 
@@ -573,7 +597,7 @@ int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s) {
 
 #define DGP_INST(T)                                                                                              \
   template int posterior_cov<T>(const T*, long, long, T*, hipStream_t);                                          \
-  template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*);                     \
+  template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*);                     \
   template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t);                                          \
   template int lauum<T>(const T*, long, T*, hipStream_t);                                                        \
   template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t);                             \

@@ -28,7 +28,7 @@ long gram_grad_partials(long N);  // number of T elements `partials` must hold
 // ---- dgp_chol.hip ---------------------------------------------------------------------------
 template <typename T>
 int potrf(T* A, long N, T* Dinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
-          hipEvent_t* syrk_ev /* 2 per bulk launch, or null */, int* n_syrk);
+          hipEvent_t* syrk_ev /* 2 per bulk launch, or null */, int* n_syrk, double* syrk_flop);
 template <typename T>
 int trtri(const T* L, const T* Dinv, long N, T* Tm, T* W, hipStream_t s);
 template <typename T>

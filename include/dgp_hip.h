@@ -120,7 +120,8 @@ int dgp_posterior_cov(dgp_plan* plan, const double* theta_host, const void* Xs_d
 #define DGP_TIME_LAUUM 5     /* lauum kernel */
 #define DGP_TIME_SOLVE 6     /* triangular solves */
 #define DGP_TIME_GRAD 7      /* gram_grad + reduction */
-#define DGP_TIME_COUNT 8
+#define DGP_TIME_SYRK_FLOP 8 /* algorithmic flops of those bulk launches (not a time) */
+#define DGP_TIME_COUNT 9
 int dgp_plan_set_timing(dgp_plan* plan, int enabled);
 int dgp_plan_get_timing(dgp_plan* plan, double* ms_out);
 
