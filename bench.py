@@ -166,9 +166,21 @@ def main():
         dom = max(stages, key=lambda k: stages[k]["ms"])
         ach = stages[dom]["tflops"]
         gram_bytes = N * (N + 64) / 2 * esz + n * d * esz
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, gfx950 half-count correction applied: scripts/pmc_summary.py); only valid
+        # for the shape those passes were taken at
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_n8192_f64.json")
+        if os.path.exists(pmc_path) and (n, d, args.dtype) == (8192, 3, "f64"):
+            try:
+                pk = json.load(open(pmc_path))["kernels"]
+                key = next(k for k in pk if k.startswith(dom))
+                traffic = pk[key]["hbm_bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
         roofline = {
             "bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak if ach else None, "traffic": None,
+            "frac": ach / peak if ach else None, "traffic": traffic,
             "launches_per_step": stages[dom]["launches"], "ms_per_step": stages[dom]["ms"],
             "stages_tflops": {k: v["tflops"] for k, v in stages.items()},
             "stages_ms": {"gram": ms[_lib.TIME_GRAM], "potrf_wall": ms[_lib.TIME_POTRF], "syrk_sum": ms[_lib.TIME_SYRK_SUM],

@@ -73,4 +73,13 @@ __device__ __forceinline__ void tri_decode(int idx, int& bi, int& bj) {
   bj = idx - i * (i + 1) / 2;
 }
 
+// XCD-aware block remap (cdna_hip_programming.md T1, bijective form): hardware deals consecutive
+// workgroup ids round-robin over the 8 XCDs, each with a private L2.  After the remap the ids that land
+// on one XCD are CONSECUTIVE in the logical tile order, so neighbouring tiles (which share operand
+// panels) hit the same L2.  A speed hint only: nothing depends on the actual placement.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 }  // namespace dgp
