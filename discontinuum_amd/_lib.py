@@ -50,6 +50,9 @@ SIGNATURES = {
     "dgp_predict_workspace_bytes": (_sz, [_vp, _i64]),
     "dgp_predict": (_i, [_vp, _dp, _vp, _i64, _vp, _sz, _vp, _vp, _vp]),
     "dgp_posterior_cov": (_i, [_vp, _dp, _vp, _i64, _vp, _sz, _vp, _vp, _vp]),
+    "dgp_mean_vjp_workspace_bytes": (_sz, [_vp, _i64]),
+    "dgp_predict_mean": (_i, [_vp, _dp, _vp, _i64, _vp, _sz, _vp, _vp]),
+    "dgp_mean_vjp": (_i, [_vp, _dp, _vp, _i64, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "dgp_plan_set_timing": (_i, [_vp, _i]),
     "dgp_plan_get_timing": (_i, [_vp, _dp]),
     "dgp_stage_gram": (_i, [_vp, _dp, _vp, _vp]),

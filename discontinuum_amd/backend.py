@@ -194,6 +194,42 @@ class GPPlan:
             L = torch.tril(cov[:m, :m]).clone()
         return mean, L
 
+    def _vjp_workspace(self, m):
+        need = int(self.lib.dgp_mean_vjp_workspace_bytes(self._h, m))
+        ws = getattr(self, "_vjp_ws", None)
+        if ws is None or ws.numel() < need + 256:
+            self._vjp_ws = ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = ws.data_ptr()
+        return C.c_void_p(base + (-base) % 256), need
+
+    def predict_mean(self, theta, Xs: torch.Tensor):
+        """K(X*, X) alpha from the held factorisation (no variance work)."""
+        th = _theta_array(theta, self.ntheta)
+        m = Xs.shape[0]
+        with torch.cuda.device(self.device):
+            xs = Xs.contiguous()
+            work, need = self._vjp_workspace(m)
+            mean = torch.empty(m, dtype=self.dtype, device=self.device)
+            _lib.check(self.lib.dgp_predict_mean(self._h, th, _ptr(xs), m, work, need, _ptr(mean), _stream()), "dgp_predict_mean")
+        return mean
+
+    def mean_vjp(self, theta, Xs: torch.Tensor, w: torch.Tensor):
+        """Vector-Jacobian product of ``predict_mean``: (dtheta[P], dr[n], dnoise[n]) for upstream w[m]."""
+        th = _theta_array(theta, self.ntheta)
+        m = Xs.shape[0]
+        self._check_vec(w, "w", m)
+        with torch.cuda.device(self.device):
+            xs = Xs.contiguous()
+            work, need = self._vjp_workspace(m)
+            dtheta = torch.zeros(_lib.OUT_LEN, dtype=self.dtype, device=self.device)
+            dr = torch.empty(self.n, dtype=self.dtype, device=self.device)
+            dnoise = torch.empty(self.n, dtype=self.dtype, device=self.device)
+            _lib.check(
+                self.lib.dgp_mean_vjp(self._h, th, _ptr(xs), m, _ptr(w), work, need, _ptr(dtheta), _ptr(dr), _ptr(dnoise), _stream()),
+                "dgp_mean_vjp",
+            )
+        return dtheta[: self.ntheta], dr, dnoise
+
     def potrf_info(self) -> int:
         """info of the last factorisation (0 = ok, k = first non-positive pivot), synchronising."""
         off = self._info_offset()

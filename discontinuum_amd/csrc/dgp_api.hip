@@ -28,7 +28,7 @@ struct dgp_plan {
   void *Xt, *A, *Tm, *S, *z, *alpha, *gpart, *spart, *scal;
   int* info;
   int lookahead;
-  int have_inputs, have_factor;
+  int have_inputs, have_factor, have_inverse;
   hipStream_t s2;
   hipEvent_t* ev;
   int nev;
@@ -267,6 +267,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
   if ((rc = run_solve<T>(p, r, s))) return rc;
   tick(p, TS_SOLVE, 1, s);
   p->timed_valid = 0;
+  p->have_inverse = 0;
   if (with_grad) {
     tick(p, TS_LAUUM, 0, s);
     if ((rc = run_lauum<T>(p, s))) return rc;
@@ -275,6 +276,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
     if ((rc = run_grad<T>(p, theta, (T*)out + DGP_OUT_DTHETA, s))) return rc;
     tick(p, TS_GRAD, 1, s);
     p->timed_valid = p->timing && p->tev;
+    p->have_inverse = 1;
     if (dnoise && (rc = finish<T>((const T*)p->S, (const T*)p->alpha, p->N, (int)p->n, (T*)dnoise, s))) return rc;
     if (dr) copy_n_kernel<T><<<(unsigned)((p->n + 255) / 256), 256, 0, s>>>((const T*)p->alpha, p->n, (T*)dr);
   }
@@ -333,6 +335,69 @@ static int post_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t m,
   if (he != hipSuccess) return (int)he;
   if ((rc = gram_sym<T>(p->model, p->d, Xst, M, (int)m, theta, vpad, (T*)cov, s))) return rc;
   return posterior_cov<T>(V, p->N, M, (T*)cov, s);
+}
+
+struct VjpLayout {
+  size_t Xst, Ks, g, beta, part, spart, total;
+};
+static VjpLayout vjp_layout(const dgp_plan* p, int64_t m) {
+  const size_t M = (size_t)round_up(m, DGP_TILE_HOST), e = p->elem, N = (size_t)p->N;
+  const size_t nb = N / 64, blocks_sym = nb * (nb + 1) / 2, blocks_cross = (M / 64) * nb;
+  VjpLayout L;
+  size_t o = 0;
+  L.Xst = o; o += align_up(e * M * p->d);
+  L.Ks = o; o += align_up(e * N * M);
+  L.g = o; o += align_up(e * N);
+  L.beta = o; o += align_up(e * N);
+  L.part = o; o += align_up(e * 24 * (blocks_sym > blocks_cross ? blocks_sym : blocks_cross));
+  L.spart = o; o += align_up(e * (size_t)solve_partials(p->N));
+  L.total = o;
+  return L;
+}
+
+template <typename T>
+__global__ void matvec_cols_kernel(const T* Ks, long N, long Mp, int n, const T* alpha, T* out) {
+  // out[j] = sum_i Ks[i][j] alpha_i : one thread per column, coalesced across columns
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= Mp) return;
+  T acc = T(0);
+  for (long i = 0; i < n; ++i) acc += Ks[i * Mp + j] * alpha[i];
+  out[j] = acc;
+}
+
+template <typename T>
+static int predict_mean(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* mean,
+                        hipStream_t s) {
+  const VjpLayout L = vjp_layout(p, m);
+  const long M = round_up(m, DGP_TILE_HOST);
+  char* w = (char*)work;
+  int rc = cross<T>(p, theta, Xs, m, w + L.Xst, w + L.Ks, s);
+  if (rc) return rc;
+  matvec_cols_kernel<T><<<(unsigned)((M + 255) / 256), 256, 0, s>>>((const T*)(w + L.Ks), p->N, M, (int)p->n,
+                                                                  (const T*)p->alpha, (T*)(w + L.g));
+  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>((const T*)(w + L.g), m, (T*)mean);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m, const void* wts, void* work,
+                    void* dtheta, void* dr, void* dnoise, hipStream_t s) {
+  const VjpLayout L = vjp_layout(p, m);
+  const long M = round_up(m, DGP_TILE_HOST);
+  char* w = (char*)work;
+  T* Xst = (T*)(w + L.Xst);
+  T* Ks = (T*)(w + L.Ks);
+  T* g = (T*)(w + L.g);
+  T* beta = (T*)(w + L.beta);
+  int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s);
+  if (rc) return rc;
+  if ((rc = gemv_rows<T>(Ks, p->N, M, (int)m, (const T*)wts, g, s))) return rc;             // g = K(X, X*) w
+  if ((rc = symv_lower<T>((const T*)p->S, p->N, g, (int)p->n, (const T*)p->alpha, beta, (T*)(w + L.spart),
+                          (T*)dnoise, s)))                                                   // beta = K^^-1 g
+    return rc;
+  if (dr) copy_n_kernel<T><<<(unsigned)((p->n + 255) / 256), 256, 0, s>>>(beta, p->n, (T*)dr);
+  return mean_vjp_grad<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, Xst, M, (int)m, theta, (const T*)p->alpha,
+                          beta, (const T*)wts, (T*)(w + L.part), (T*)dtheta, s);
 }
 
 #define DGP_BY_DTYPE(p, CALL64, CALL32) ((p)->dtype == DGP_F64 ? (CALL64) : (CALL32))
@@ -407,6 +472,31 @@ int dgp_posterior_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t 
   int rc = DGP_BY_DTYPE(p, post_cov<double>(p, theta, Xs, m, work, mean, cov, s),
                         post_cov<float>(p, theta, Xs, m, work, mean, cov, s));
   return wrap(rc, "dgp_posterior_cov");
+}
+
+size_t dgp_mean_vjp_workspace_bytes(const dgp_plan* p, int64_t m) { return (p && m > 0) ? vjp_layout(p, m).total : 0; }
+
+int dgp_predict_mean(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
+                     void* mean, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!theta || !Xs || !work || !mean || m <= 0) return fail(DGP_E_ARG, "dgp_predict_mean: null argument");
+  if (!p->have_factor) return fail(DGP_E_STATE, "dgp_predict_mean: no factorisation in the plan");
+  if (work_bytes < dgp_mean_vjp_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_predict_mean: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  return wrap(DGP_BY_DTYPE(p, predict_mean<double>(p, theta, Xs, m, work, mean, s),
+                           predict_mean<float>(p, theta, Xs, m, work, mean, s)), "dgp_predict_mean");
+}
+
+int dgp_mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m, const void* wts, void* work,
+                 size_t work_bytes, void* dtheta, void* dr, void* dnoise, void* stream) {
+  DGP_CHECK_PLAN(p);
+  if (!theta || !Xs || !wts || !work || !dtheta || m <= 0) return fail(DGP_E_ARG, "dgp_mean_vjp: null argument");
+  if (!p->have_factor || !p->have_inverse)
+    return fail(DGP_E_STATE, "dgp_mean_vjp: needs K^^-1 and alpha from dgp_fit_step at the same theta");
+  if (work_bytes < dgp_mean_vjp_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_mean_vjp: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  return wrap(DGP_BY_DTYPE(p, mean_vjp<double>(p, theta, Xs, m, wts, work, dtheta, dr, dnoise, s),
+                           mean_vjp<float>(p, theta, Xs, m, wts, work, dtheta, dr, dnoise, s)), "dgp_mean_vjp");
 }
 
 int dgp_plan_set_timing(dgp_plan* p, int enabled) {

@@ -499,6 +499,56 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ z, lon
   if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// beta = S g for a symmetric matrix stored in its lower triangle (diagonal tiles hold both halves):
+// row part  sum_{j <= i} S[i][j] g_j  +  column part  sum_{i > j} S[i][j] g_i
+template <typename T>
+__global__ __launch_bounds__(256) void symv_row_kernel(const T* __restrict__ S, long ld, const T* __restrict__ g,
+                                                       T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const T* row = S + i * ld;
+  T acc = T(0);
+  for (long j = lane; j <= i; j += 64) acc += row[j] * g[j];
+  acc = wave_sum(acc);
+  if (lane == 0) out[i] = acc;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void symv_col_kernel(const T* __restrict__ S, long ld, const T* __restrict__ g,
+                                                       T* __restrict__ partial) {
+  __shared__ T red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long j = (long)blockIdx.x * 64 + tx;
+  const long r0 = (long)blockIdx.y * DGP_TRMV_CHUNK, r1 = min(r0 + (long)DGP_TRMV_CHUNK, ld);
+  const long rstart = max(r0, (long)blockIdx.x * 64);
+  T acc = T(0);
+  for (long i = rstart + ty; i < r1; i += 4) acc += (i > j) ? S[i * ld + j] * g[i] : T(0);
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0) partial[(long)blockIdx.y * ld + j] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void symv_finish_kernel(const T* __restrict__ partial, long N, int nchunks,
+                                                          const T* __restrict__ alpha, int n, T* __restrict__ beta,
+                                                          T* __restrict__ dnoise) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  T acc = beta[j];  // row part
+  for (int c = (int)(j / DGP_TRMV_CHUNK); c < nchunks; ++c) acc += partial[(long)c * N + j];
+  acc = j < n ? acc : T(0);
+  beta[j] = acc;
+  if (j < n && dnoise) dnoise[j] = -acc * alpha[j];
+}
+
+template <typename T>
+int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T* partials, T* dnoise, hipStream_t s) {
+  const int nchunks = (int)((N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK);
+  symv_row_kernel<T><<<(unsigned)(N / 4), 256, 0, s>>>(S, N, g, beta);
+  dim3 grid((unsigned)(N / 64), (unsigned)nchunks);
+  symv_col_kernel<T><<<grid, 256, 0, s>>>(S, N, g, partials);
+  symv_finish_kernel<T><<<(unsigned)((N + 255) / 256), 256, 0, s>>>(partials, N, nchunks, alpha, n, beta, dnoise);
+  return (int)hipGetLastError();
+}
+
 long solve_partials(long N) { return (N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK * N; }
 
 template <typename T>
@@ -597,6 +647,7 @@ int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s) {
 
 #define DGP_INST(T)                                                                                              \
   template int posterior_cov<T>(const T*, long, long, T*, hipStream_t);                                          \
+  template int symv_lower<T>(const T*, long, const T*, int, const T*, T*, T*, T*, hipStream_t);                  \
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*);                     \
   template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t);                                          \
   template int lauum<T>(const T*, long, T*, hipStream_t);                                                        \

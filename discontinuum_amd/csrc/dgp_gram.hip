@@ -151,11 +151,13 @@ __global__ __launch_bounds__(256) void gram_diag_kernel(const T* __restrict__ Xs
 }
 
 // ------------------------------------------------------------------------------------------
-template <typename T, typename M>
+// MODE 0: weights W_ij = S_ij - a_i a_j            (marginal likelihood:  1/2 tr((K^-1 - a a^T) dK))
+// MODE 1: weights W_ij = -(b_i a_j + b_j a_i)       (predictive-mean VJP:  -b^T dK a, symmetrised; S unused)
+template <typename T, typename M, int MODE>
 __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt, long N, int n, const typename M::Pre pre,
                                                         const T* __restrict__ S, const T* __restrict__ alpha,
-                                                        T* __restrict__ partials) {
-  __shared__ T sfi[M::NF][64], sfj[M::NF][64], sai[64], saj[64];
+                                                        const T* __restrict__ beta, T* __restrict__ partials) {
+  __shared__ T sfi[M::NF][64], sfj[M::NF][64], sai[64], saj[64], sbi[64], sbj[64];
   __shared__ T red[4][M::NTHETA];
   int bi, bj;
   tri_decode(blockIdx.x, bi, bj);
@@ -163,16 +165,19 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt
   if (t < 64) {
     stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
     sai[t] = alpha[(long)bi * 64 + t];
+    sbi[t] = MODE == 1 ? beta[(long)bi * 64 + t] : T(0);
   } else if (t < 128) {
     stage_strip<T, M>(Xt, N, (long)bj * 64, pre, sfj, t - 64);
     saj[t - 64] = alpha[(long)bj * 64 + t - 64];
+    sbj[t - 64] = MODE == 1 ? beta[(long)bj * 64 + t - 64] : T(0);
   }
   __syncthreads();
   const int ty = t >> 4, tx = t & 15;
-  T fj[4][M::NF], aj[4];
+  T fj[4][M::NF], aj[4], bjv[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     aj[b] = saj[tx * 4 + b];
+    bjv[b] = sbj[tx * 4 + b];
 #pragma unroll
     for (int c = 0; c < M::NF; ++c) fj[b][c] = sfj[c][tx * 4 + b];
   }
@@ -186,14 +191,14 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt
     T fi[M::NF];
 #pragma unroll
     for (int c = 0; c < M::NF; ++c) fi[c] = sfi[c][ty * 4 + a];
-    const T ai = sai[ty * 4 + a];
-    T sv[4];
-    load4<T>(S + gi * N + (long)bj * 64 + tx * 4, sv);
+    const T ai = sai[ty * 4 + a], bi_ = sbi[ty * 4 + a];
+    T sv[4] = {T(0), T(0), T(0), T(0)};
+    if (MODE == 0) load4<T>(S + gi * N + (long)bj * 64 + tx * 4, sv);
 #pragma unroll 1
     for (int b = 0; b < 4; ++b) {
       const long gj = (long)bj * 64 + tx * 4 + b;
       // lower triangle counted once with weight 1 (= 1/2 * 2), diagonal with 1/2, pad with 0
-      T w = sv[b] - ai * aj[b];
+      T w = MODE == 0 ? sv[b] - ai * aj[b] : -(bi_ * aj[b] + bjv[b] * ai);
       w = (gj > gi || gi >= n) ? T(0) : (gj == gi ? T(0.5) * w : w);
       (void)M::template pair<true>(fi, fj[b], pre, w, acc);
     }
@@ -208,10 +213,72 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt
   if (t < M::NTHETA) partials[(long)blockIdx.x * DGP_MAX_THETA + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
 
+// dL/dtheta_p += sum_{i train, j test} a_i w_j dk(x_i, x*_j)/dtheta_p   (rectangular, no symmetry)
+template <typename T, typename M>
+__global__ __launch_bounds__(256) void gram_cross_grad_kernel(const T* __restrict__ Xt, long N, int n,
+                                                              const T* __restrict__ Xst, long Mp, int m,
+                                                              const typename M::Pre pre, const T* __restrict__ alpha,
+                                                              const T* __restrict__ wts, T* __restrict__ partials) {
+  __shared__ T sfi[M::NF][64], sfj[M::NF][64], sai[64], swj[64];
+  __shared__ T red[4][M::NTHETA];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int t = threadIdx.x;
+  if (t < 64) {
+    stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
+    sai[t] = alpha[(long)bi * 64 + t];
+  } else if (t < 128) {
+    stage_strip<T, M>(Xst, Mp, (long)bj * 64, pre, sfj, t - 64);
+    const long j = (long)bj * 64 + t - 64;
+    swj[t - 64] = j < m ? wts[j] : T(0);
+  }
+  __syncthreads();
+  const int ty = t >> 4, tx = t & 15;
+  T acc[M::NTHETA];
+#pragma unroll
+  for (int p = 0; p < M::NTHETA; ++p) acc[p] = T(0);
+#pragma unroll 1
+  for (int a = 0; a < 4; ++a) {
+    const long gi = (long)bi * 64 + ty * 4 + a;
+    T fi[M::NF];
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fi[c] = sfi[c][ty * 4 + a];
+    const T ai = gi < n ? sai[ty * 4 + a] : T(0);
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
+      T fj[M::NF];
+#pragma unroll
+      for (int c = 0; c < M::NF; ++c) fj[c] = sfj[c][tx * 4 + b];
+      (void)M::template pair<true>(fi, fj, pre, ai * swj[tx * 4 + b], acc);
+    }
+  }
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int p = 0; p < M::NTHETA; ++p) {
+    T v = wave_sum(acc[p]);
+    if (lane == 0) red[wv][p] = v;
+  }
+  __syncthreads();
+  const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  if (t < M::NTHETA) partials[blk * DGP_MAX_THETA + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
+
+// g_i = sum_j Ks[i][j] w_j  (N x Mp row-major, one wave per row)
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ Ks, long N, long Mp, int m,
+                                                        const T* __restrict__ w, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  T acc = T(0);
+  for (long j = lane; j < m; j += 64) acc += Ks[i * Mp + j] * w[j];
+  acc = wave_sum(acc);
+  if (lane == 0) out[i] = acc;
+}
+
 // deterministic second stage: one block, fixed summation order
 template <typename T>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ partials, long nblk, int nt,
-                                                          T* __restrict__ out) {
+                                                          T* __restrict__ out, int accumulate) {
   __shared__ T red[256];
   for (int p = 0; p < nt; ++p) {
     T v = T(0);
@@ -222,7 +289,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ 
       if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0) out[p] = red[0];
+    if (threadIdx.x == 0) out[p] = accumulate ? out[p] + red[0] : red[0];
     __syncthreads();
   }
 }
@@ -295,8 +362,35 @@ int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta,
   const long nb = N / 64;
   const long nblk = nb * (nb + 1) / 2;
   DGP_DISPATCH_MODEL(model, d,
-                     (gram_grad_kernel<T, M><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), S, alpha, partials)));
-  grad_reduce_kernel<T><<<dim3(1), dim3(256), 0, s>>>(partials, nblk, nt, dtheta);
+                     (gram_grad_kernel<T, M, 0><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), S, alpha,
+                                                                                          nullptr, partials)));
+  grad_reduce_kernel<T><<<dim3(1), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0);
+  return (int)hipGetLastError();
+}
+
+// dtheta = -b^T dK a (symmetric part) + sum_ij a_i w_j dK*_ij   -- the two kernel-gradient terms of the mean VJP
+template <typename T>
+int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,
+                  const T* alpha, const T* beta, const T* wts, T* partials, T* dtheta, hipStream_t s) {
+  const int nt = model_ntheta(model, d);
+  if (nt < 0) return -2;
+  const long nb = N / 64;
+  const long nblk = nb * (nb + 1) / 2;
+  DGP_DISPATCH_MODEL(model, d,
+                     (gram_grad_kernel<T, M, 1><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), nullptr,
+                                                                                          alpha, beta, partials)));
+  grad_reduce_kernel<T><<<dim3(1), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0);
+  dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64));
+  DGP_DISPATCH_MODEL(model, d,
+                     (gram_cross_grad_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xt, N, n, Xst, Mp, m, M::prepare(theta), alpha, wts,
+                                                                             partials)));
+  grad_reduce_kernel<T><<<dim3(1), dim3(256), 0, s>>>(partials, (long)grid.x * grid.y, nt, dtheta, 1);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream_t s) {
+  gemv_rows_kernel<T><<<(unsigned)((N + 3) / 4), 256, 0, s>>>(Ks, N, Mp, m, w, out);
   return (int)hipGetLastError();
 }
 
@@ -305,7 +399,10 @@ int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta,
   template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t);             \
   template int gram_cross<T>(int, int, const T*, long, int, const T*, long, int, const double*, T*, hipStream_t); \
   template int gram_diag<T>(int, int, const T*, long, int, const double*, T*, hipStream_t);                      \
-  template int gram_grad<T>(int, int, const T*, long, int, const double*, const T*, const T*, T*, T*, hipStream_t);
+  template int gram_grad<T>(int, int, const T*, long, int, const double*, const T*, const T*, T*, T*, hipStream_t); \
+  template int mean_vjp_grad<T>(int, int, const T*, long, int, const T*, long, int, const double*, const T*, const T*, \
+                                const T*, T*, T*, hipStream_t);                                                    \
+  template int gemv_rows<T>(const T*, long, long, int, const T*, T*, hipStream_t);
 DGP_INST(double)
 DGP_INST(float)
 

@@ -23,7 +23,12 @@ int gram_diag(int model, int d, const T* Xst, long M, int m, const double* theta
 template <typename T>
 int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
               T* partials, T* dtheta, hipStream_t s);
-long gram_grad_partials(long N);  // number of T elements `partials` must hold
+long gram_grad_partials(long N);
+template <typename T>
+int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,
+                  const T* alpha, const T* beta, const T* wts, T* partials, T* dtheta, hipStream_t s);
+template <typename T>
+int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream_t s);  // number of T elements `partials` must hold
 
 // ---- dgp_chol.hip ---------------------------------------------------------------------------
 template <typename T>
@@ -41,6 +46,8 @@ template <typename T>
 int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* mean, T* var,
                 hipStream_t s);
 long solve_partials(long N);
+template <typename T>
+int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T* partials, T* dnoise, hipStream_t s);
 // cov (M x M) = Kss - V^T V, lower tiles; Kss already holds K(Xs, Xs) (identity pad)
 template <typename T>
 int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s);

@@ -24,7 +24,7 @@ import tqdm
 
 from ..backend import GPPlan
 from ..gp.lowering import lower
-from ..gp.mll import ExactMarginalLogLikelihood, NotPSDError
+from ..gp.mll import ExactMarginalLogLikelihood, NotPSDError, predictive_mean
 from ..xr_compat import DataArray
 from .base import BaseModel, is_fitted
 
@@ -87,6 +87,18 @@ class MarginalHIP(BaseModel):
             mean=self.model.prior_mean(self._train_x),
             noise=self.likelihood.train_noise(self._train_x.device, self.dtype),
         )
+
+    def _differentiable_mean(self, x: torch.Tensor):
+        """Posterior mean at model-space points ``x`` WITH gradients to every hyperparameter
+        (``likelihood(model(x)).mean`` inside the reference's penalty callback,
+        src/rating_gp/models/gpytorch.py:160-176).  Valid inside a training iteration, after the marginal
+        likelihood of that iteration has been evaluated (the plan holds its factorisation)."""
+        x = x.to(self.device, self.dtype).contiguous()
+        if hasattr(self.model, "prepare_eval"):
+            self.model.prepare_eval(self._train_x, x)
+        spec = self._prior()
+        r = (self._train_y - spec.mean).contiguous()
+        return predictive_mean(self._plan, spec.theta, r, spec.noise.contiguous(), x) + self.model.prior_mean(x)
 
     def _param_key(self):
         return tuple(float(v) for p in self.model.parameters() for v in p.detach().reshape(-1).tolist())

@@ -44,6 +44,29 @@ class _ExactGPNLL(torch.autograd.Function):
         return None, (dtheta * g).to(ctx.theta_dtype), dr * gd, dnoise * gd
 
 
+class _PredictiveMean(torch.autograd.Function):
+    """K(X*, X; theta) K^^-1 r as a differentiable function of (theta, r, noise): forward is
+    ``dgp_predict_mean``, backward ``dgp_mean_vjp``.  Both read the factorisation the plan holds from the
+    fit step at the same hyperparameters -- which is how the reference's penalty callback is used: it runs
+    inside the training iteration, right after the marginal likelihood (engines/gpytorch.py:350-373)."""
+
+    @staticmethod
+    def forward(ctx, plan, theta, r, noise, Xs):
+        ctx.plan, ctx.theta_dtype = plan, theta.dtype
+        ctx.save_for_backward(theta.detach(), Xs)
+        return plan.predict_mean(theta, Xs)
+
+    @staticmethod
+    def backward(ctx, g):
+        theta, Xs = ctx.saved_tensors
+        dtheta, dr, dnoise = ctx.plan.mean_vjp(theta, Xs, g.contiguous())
+        return None, dtheta.to("cpu", ctx.theta_dtype), dr, dnoise, None
+
+
+def predictive_mean(plan, theta, r, noise, Xs):
+    return _PredictiveMean.apply(plan, theta, r, noise, Xs)
+
+
 def exact_gp_nll(plan, theta, r, noise):
     """Differentiable data term with gpytorch's jitter-retry policy. Returns a 0-dim CPU float64 tensor."""
     jitter0 = 1e-8 if plan.dtype == torch.float64 else 1e-6

@@ -71,9 +71,38 @@ class RatingGPMarginalHIP(RatingDataMixin, MarginalHIP):
                       patience=patience, scheduler=scheduler, resume=resume)
         if monotonic_penalty_weight <= 0:
             return super().fit(**common, penalty_callback=None, penalty_weight=0.0)
-        raise NotImplementedError(
-            "monotonic_penalty_weight > 0 needs the differentiable predictive mean (SURVEY.md section 8 row f4), "
-            "which the HIP engine does not provide yet")
+
+        step = {"i": 0}
+
+        def penalty_callback():
+            # optionally skip iterations (the skipped ones are compensated by the interval factor below)
+            step["i"] += 1
+            if monotonic_penalty_interval > 1 and (step["i"] % monotonic_penalty_interval) != 0:
+                return torch.zeros((), device=self._train_x.device, dtype=self.dtype)
+            # random grid in model space: time uniform, stage log-uniform (denser at low stage)
+            time_dim, stage_dim = 0, 1
+            x_min, x_max = self.dm.X.min(axis=0), self.dm.X.max(axis=0)
+            dev = self._train_x.device
+            u_time = torch.rand((grid_size,), dtype=self.dtype, device=dev)
+            time_grid = u_time * (x_max[time_dim] - x_min[time_dim]) + x_min[time_dim]
+            eps = 1e-6
+            log_lo, log_hi = float(np.log(x_min[stage_dim] + eps)), float(np.log(x_max[stage_dim] + eps))
+            u_stage = torch.rand((grid_size,), dtype=self.dtype, device=dev)
+            stage_grid = torch.exp(u_stage * (log_hi - log_lo) + log_lo)
+            x_grid = torch.stack([time_grid, stage_grid], dim=1)
+            # finite difference in stage of the posterior mean (same fd_eps as the reference); both sets of
+            # points go through one differentiable predictive-mean call
+            fd_eps = 1e-3
+            x_plus = x_grid.clone()
+            x_plus[:, stage_dim] = x_grid[:, stage_dim] + fd_eps
+            mean = self._differentiable_mean(torch.cat([x_grid, x_plus], dim=0))
+            d_mean_d_stage = (mean[grid_size:] - mean[:grid_size]) / fd_eps
+            pen = torch.clamp(-d_mean_d_stage, min=0.0).mean()
+            if monotonic_penalty_interval > 1:
+                pen = pen * float(monotonic_penalty_interval)
+            return pen
+
+        return super().fit(**common, penalty_callback=penalty_callback, penalty_weight=float(monotonic_penalty_weight))
 
 
 class ExactGPModel(gp.ExactGP):

@@ -109,6 +109,20 @@ int dgp_predict(dgp_plan* plan, const double* theta_host, const void* Xs_dev, in
 int dgp_posterior_cov(dgp_plan* plan, const double* theta_host, const void* Xs_dev, int64_t m, void* work_dev,
                       size_t work_bytes, void* mean_dev, void* cov_dev, void* stream);
 
+/* Predictive mean only, and its vector-Jacobian product -- what the rating-gp monotonicity penalty
+ * differentiates (src/rating_gp/models/gpytorch.py:130-187: mean of likelihood(model(x_grid)) with grad).
+ *   dgp_predict_mean : mean_dev[j] = K(x*_j, X) alpha                                  (m entries)
+ *   dgp_mean_vjp     : given w_dev[j] = dLoss/dmean[j], with g = K(X, X*) w and beta = K^^-1 g:
+ *        dtheta_dev[p] = sum_ij alpha_i w_j dK*_ij/dtheta_p - beta^T (dK/dtheta_p) alpha   (ntheta entries)
+ *        dr_dev        = beta                       (dLoss/dr,     n entries)
+ *        dnoise_dev    = -beta * alpha              (dLoss/dnoise, n entries)
+ * Both use the factorisation (alpha, K^^-1) left in the plan by dgp_fit_step at the SAME theta. */
+size_t dgp_mean_vjp_workspace_bytes(const dgp_plan* plan, int64_t m);
+int dgp_predict_mean(dgp_plan* plan, const double* theta_host, const void* Xs_dev, int64_t m, void* work_dev,
+                     size_t work_bytes, void* mean_dev, void* stream);
+int dgp_mean_vjp(dgp_plan* plan, const double* theta_host, const void* Xs_dev, int64_t m, const void* w_dev,
+                 void* work_dev, size_t work_bytes, void* dtheta_dev, void* dr_dev, void* dnoise_dev, void* stream);
+
 /* In-library HIP-event timing of the stages of dgp_fit_step (events are recorded on the stream each
  * kernel is launched on, including the internal lookahead stream).  dgp_plan_get_timing synchronises
  * on the events of the most recent fit step and fills ms_out[DGP_TIME_COUNT]. */

@@ -52,6 +52,18 @@ class OraclePlan:
         mu, var = orc.posterior(self.model, self.X, r, noise, theta, Xs.double())
         return mu.to(self.dtype), var.to(self.dtype)
 
+    def predict_mean(self, theta, Xs):
+        theta, r, noise = self._state
+        mu, _ = orc.posterior(self.model, self.X, r, noise, theta, Xs.double())
+        return mu.to(self.dtype)
+
+    def mean_vjp(self, theta, Xs, w):
+        th, r, noise = (t.clone().requires_grad_(True) for t in self._state)
+        with torch.enable_grad():
+            mu, _ = orc.posterior(self.model, self.X, r, noise, th, Xs.double())
+            g = torch.autograd.grad((mu * w.double()).sum(), (th, r, noise))
+        return tuple(t.to(self.dtype) for t in g)
+
     def posterior_factor(self, theta, Xs):
         theta, r, noise = self._state
         mu, cov = orc.posterior(self.model, self.X, r, noise, theta, Xs.double(), full_cov=True)

@@ -149,8 +149,17 @@ def test_rating_fit_and_predict():
     assert np.all(np.isfinite(target.values))
     b = m.model.powerlaw.b.item()
     assert 1.2 <= b <= 2.5
-    with pytest.raises(NotImplementedError):
-        m.fit(cov, tgt, target_unc=unc, iterations=2, monotonic_penalty_weight=0.5)
+    # monotonicity penalty (reference: tests/test_rating_gp.py:52-65): differentiable predictive mean
+    m2 = RatingGP()
+    m2.fit(cov, tgt, target_unc=unc, iterations=5, monotonic_penalty_weight=0.5, grid_size=16, scheduler=False)
+    assert m2.is_fitted
+    # the penalty's gradient reaches kernel, mean and noise parameters
+    m2.model.zero_grad(set_to_none=True)
+    x = torch.tensor(m2.X[:6]).clone()
+    mu = m2._differentiable_mean(x)
+    mu.sum().backward()
+    grads = [p.grad for p in m2.model.parameters()]
+    assert all(g is not None for g in grads) and any(float(g.abs().sum()) > 0 for g in grads)
 
 
 def test_lowering_rejects_other_structures():

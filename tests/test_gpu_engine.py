@@ -92,3 +92,26 @@ def test_fp32_engine_runs(gpu_device):
     m.fit(cov, tgt, iterations=5)
     target, se = m.predict(cov)
     assert np.all(np.isfinite(target.values))
+
+
+def test_rating_monotonic_penalty_fit(gpu_device):
+    """The reference's third smoke test (tests/test_rating_gp.py:52-65): fit with the monotonicity penalty."""
+    from discontinuum_amd.rating_gp import RatingGP
+
+    torch.manual_seed(2)
+    cov, tgt, unc = rating_dataset(120)
+    m = RatingGP()
+    m.fit(cov, tgt, target_unc=unc, iterations=5, monotonic_penalty_weight=0.5, grid_size=16, scheduler=False)
+    assert m.is_fitted
+    m.model.zero_grad(set_to_none=True)
+    # penalty gradient check against the oracle at the fitted parameters (one extra evaluation)
+    from discontinuum_amd.gp.mll import ExactMarginalLogLikelihood
+
+    _ = -ExactMarginalLogLikelihood(m.likelihood, m.model)(m._prior(), m._train_y)  # refresh the plan state
+    x = torch.tensor(m.X[:10]).clone()
+    mu = m._differentiable_mean(x)
+    mu.sum().backward()
+    grads = [p.grad for p in m.model.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads)
+    target, _ = m.predict(cov)
+    assert np.all(np.isfinite(target.values))

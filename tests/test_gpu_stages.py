@@ -185,3 +185,26 @@ def test_bad_arguments_fail_loudly(gpu_device):
         p.fit_step(torch.ones(9), r, r)
     with pytest.raises(ValueError):
         p.fit_step(torch.ones(5), r, r)
+
+
+@pytest.mark.parametrize("model,d,n,m", [("rating", 2, 300, 40), ("loadest", 3, 200, 128), ("rating", 2, 100, 200)])
+def test_predictive_mean_and_vjp_fp64(model, d, n, m, gpu_device):
+    """dgp_predict_mean / dgp_mean_vjp (the differentiable mean the monotonicity penalty needs) vs autograd
+    through the oracle's dense posterior mean.  Tolerance: mean abs 1e-9, gradients rel 1e-7."""
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=11, perturb=0.2)
+    Xs, *_ = make_case(model, d, m, seed=12)
+    w = torch.randn(m, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    th, rr, nn = (t.clone().requires_grad_(True) for t in (theta, r, noise))
+    mu_ref, _ = orc.posterior(model, X, rr, nn, th, Xs)
+    g_theta, g_r, g_noise = torch.autograd.grad((mu_ref * w).sum(), (th, rr, nn))
+    p = plan_for(model, d, n, X, torch.float64, dev)
+    with pytest.raises(Exception):  # no factorisation yet
+        p.predict_mean(theta, Xs.to(dev))
+    p.fit_step(theta, r.to(dev), noise.to(dev))
+    mu = p.predict_mean(theta, Xs.to(dev))
+    assert (mu.cpu() - mu_ref.detach()).abs().max() < 1e-9
+    dtheta, dr, dnoise = p.mean_vjp(theta, Xs.to(dev), w.to(dev))
+    assert (dtheta.cpu() - g_theta).abs().max() / g_theta.abs().max() < 1e-7
+    assert (dr.cpu() - g_r).abs().max() / g_r.abs().max() < 1e-7
+    assert (dnoise.cpu() - g_noise).abs().max() / g_noise.abs().max() < 1e-7
