@@ -413,7 +413,7 @@ template <typename T>
 int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long N, T* Tm, T* W, hipStream_t s) {
   const int nbk = (int)(N / NB);
   for (int m = 1; m < nbk; m *= 2) {
-    if (m <= 8) trtri_level<T, 64>(L, Tm, W, N, m, s);
+    if (m <= 16) trtri_level<T, 64>(L, Tm, W, N, m, s);  // <= 512 tiles of 128^2 would leave the GPU waiting on the longest one
     else trtri_level<T, 128>(L, Tm, W, N, m, s);
   }
   return (int)hipGetLastError();
