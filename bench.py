@@ -3,11 +3,16 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one `dgp_fit_step` through the C ABI: Gram build, blocked Cholesky, L^-1, K^^-1, NLL and
-all hyperparameter / residual / noise gradients for one site, inputs resident in HBM
-(BASELINE.json configs[1]).  With N > 1 every rank owns one independent site
-(seed = rank, weak scaling, no data-path collective); the only RCCL traffic is the gather of the
-(NLL, gradient) vectors at the end of the timed region.  Rank 0 prints ONE JSON line.
+One "fit" = one `dgp_fit_step` through the C ABI: Gram build, blocked Cholesky, L^-1, K^^-1, NLL and all
+hyperparameter / residual / noise gradients for one site, inputs resident in HBM (BASELINE.json
+configs[1]).  One "step" = one batch of `--sites-per-gpu` (default 2) INDEPENDENT
+sites per GPU, each on its own plan and HIP stream -- the north star's "independent sites /
+hyperparameter-sample batches": while one site sits in the sequential panel chain of its factorisation
+the other's GEMM-heavy stages use the idle CUs.  `value` = fits/s over all sites and GPUs; the latency of a
+single site alone on the GPU is reported next to it (`single_site`), and the roofline numbers come from
+that single-site loop (no co-running kernels).  With N > 1 every rank owns its own sites (seeds
+rank*S .. rank*S+S-1, weak scaling, no data-path collective); the only RCCL traffic is the gather of the
+(NLL, gradient) rows at the end of the timed region.  Rank 0 prints ONE JSON line.
 
 `roofline`     dominant kernel of the step, timed live with HIP events recorded inside the library on the
                stream each kernel is launched on (last timed step).  Algorithmic flops per DESIGN.md.
@@ -91,6 +96,7 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lookahead", action="store_true")
+    ap.add_argument("--sites-per-gpu", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,41 +120,65 @@ def main():
     from discontinuum_amd.sites import gather_site_results
 
     dt = torch.float64 if args.dtype == "f64" else torch.float32
-    n, d = args.n, args.d
-    X, y = synth_loadest(n, d, seed=rank)  # one independent site per rank
-    Xd = torch.tensor(X, dtype=dt, device=dev).contiguous()
-    yd = torch.tensor(y, dtype=dt, device=dev).contiguous()
-    noise = torch.full((n,), 0.01, dtype=dt, device=dev)
+    n, d, S = args.n, args.d, max(1, args.sites_per_gpu)
     ntheta = 2 * d + 5
     theta = [0.6931471805599453] * ntheta  # gpytorch defaults: softplus(0)
-    plan = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=not args.no_lookahead)
-    plan.set_inputs(Xd)
-    plan.set_timing(rank == 0)
+    noise = torch.full((n,), 0.01, dtype=dt, device=dev)
+    plans, streams, ys = [], [], []
+    for sidx in range(S):  # S independent sites per rank, each with its own plan and stream
+        X, y = synth_loadest(n, d, seed=rank * S + sidx)
+        p = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=not args.no_lookahead)
+        p.set_inputs(torch.tensor(X, dtype=dt, device=dev).contiguous())
+        plans.append(p)
+        ys.append(torch.tensor(y, dtype=dt, device=dev).contiguous())
+        streams.append(torch.cuda.Stream(device=dev))
+    plan = plans[0]
 
-    out = None
-    for _ in range(args.warmup):
-        out, _, _ = plan.fit_step(theta, yd, noise)
+    def batch_step():
+        outs = []
+        for p, st, y in zip(plans, streams, ys):
+            with torch.cuda.stream(st):
+                outs.append(p.fit_step(theta, y, noise)[0])
+        return outs
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        outs = batch_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out, dr, dn = plan.fit_step(theta, yd, noise)
+        outs = batch_step()
+    torch.cuda.synchronize()
     # the batch gather: (NLL, info, gradient) row of every site -> every rank (RCCL all_gather, 256 B per site)
-    table = gather_site_results(out.unsqueeze(0), world)
+    local = torch.stack(outs)
+    table = gather_site_results(local, world * S) if dist is not None else local
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    host = out.cpu().double()
-    assert host[_lib.OUT_INFO] == 0 and torch.isfinite(host[_lib.OUT_NLL]), "fit step failed"
-    assert table.shape[0] == world and bool(torch.isfinite(table[:, _lib.OUT_NLL]).all()), "a site failed"
+    host = local.cpu().double()
+    assert bool((host[:, _lib.OUT_INFO] == 0).all()) and bool(torch.isfinite(host[:, _lib.OUT_NLL]).all()), "fit step failed"
+    assert table.shape[0] == world * S and bool(torch.isfinite(table[:, _lib.OUT_NLL]).all()), "a site failed"
+
+    # ---- single-site loop on rank 0: latency of one fit alone on the GPU + per-kernel HIP-event timings
+    single_ms = None
+    if rank == 0:
+        plan.set_timing(True)
+        ksingle = max(3, args.steps // 2)
+        plan.fit_step(theta, ys[0], noise)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(ksingle):
+            plan.fit_step(theta, ys[0], noise)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / ksingle * 1e3
 
     if rank == 0:
         N = plan.N
@@ -186,13 +216,14 @@ def main():
             "stages_ms": {"gram": ms[_lib.TIME_GRAM], "potrf_wall": ms[_lib.TIME_POTRF], "syrk_sum": ms[_lib.TIME_SYRK_SUM],
                           "trtri": ms[_lib.TIME_TRTRI], "lauum": ms[_lib.TIME_LAUUM], "solve": ms[_lib.TIME_SOLVE],
                           "grad": ms[_lib.TIME_GRAD]},
-            "step_flops": float(N) ** 3, "step_tflops": float(N) ** 3 * args.steps / elapsed / 1e12 * 1.0,
+            "fit_flops": float(N) ** 3, "job_tflops": float(N) ** 3 * world * S * args.steps / elapsed / 1e12,
+            "measured_in": "single-site loop (one fit at a time on the GPU), last step",
             "gram_hbm": {"bound": "hbm", "achieved": gram_bytes / (ms[_lib.TIME_GRAM] * 1e-3) / 1e9 if ms[_lib.TIME_GRAM] > 0 else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes": gram_bytes},
         }
         result = {
             "metric": "GP fits/sec (NLL+grad step) at n=8192 d=3, 1/2/4/8 MI355X",
-            "value": world * args.steps / elapsed,
+            "value": world * S * args.steps / elapsed,
             "unit": "fits/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -203,9 +234,12 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"synthetic loadest-gp kernel, n={n} d={d} {args.dtype} exact GP, one site per GPU",
-                       "n": n, "d": d, "sites_per_gpu": 1, "lookahead": not args.no_lookahead,
-                       "nll": float(host[_lib.OUT_NLL])},
+            "config": {"workload": f"synthetic loadest-gp kernel, n={n} d={d} {args.dtype} exact GP, "
+                                   f"{S} independent site(s) in flight per GPU (one step = one fit of each)",
+                       "n": n, "d": d, "sites_per_gpu": S, "fits_per_step": world * S,
+                       "lookahead": not args.no_lookahead, "nll_site0": float(host[0, _lib.OUT_NLL])},
+            "single_site": {"fits_per_s": 1e3 / single_ms, "ms_per_fit": single_ms,
+                            "note": "one site alone on one GPU, steps strictly sequential (a single fit loop)"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -115,3 +115,24 @@ def test_rating_monotonic_penalty_fit(gpu_device):
     assert all(g is not None and torch.isfinite(g).all() for g in grads)
     target, _ = m.predict(cov)
     assert np.all(np.isfinite(target.values))
+
+
+def test_fit_sites_two_plans_match_sequential(gpu_device):
+    """Config-4 style batches: sites dealt over two plans/streams give the same rows as one plan."""
+    from discontinuum_amd.backend import GPPlan
+    from discontinuum_amd.sites import fit_sites
+
+    n, d, dev = 600, 3, gpu_device
+    data = []
+    for i in range(5):
+        X, y = orc.synth_loadest(n, d, seed=40 + i)
+        data.append((torch.tensor(X, device=dev), torch.tensor(y, device=dev)))
+    noise = torch.full((n,), 0.01, dtype=torch.float64, device=dev)
+    theta = [0.6931471805599453] * 11
+    one = fit_sites(GPPlan("loadest", n, d, device=dev), [x for x, _ in data], [y for _, y in data], [noise] * 5, theta)
+    two = fit_sites([GPPlan("loadest", n, d, device=dev) for _ in range(2)], [x for x, _ in data], [y for _, y in data],
+                    [noise] * 5, theta)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
+    val, g, _, _ = orc.nll_data_and_grads("loadest", data[3][0].cpu(), data[3][1].cpu(), noise.cpu(), torch.tensor(theta, dtype=torch.float64))
+    assert abs(two[3, 0].item() - val.item()) / abs(val.item()) < 1e-10
