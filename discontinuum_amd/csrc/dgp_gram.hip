@@ -279,19 +279,19 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ Ks
 template <typename T>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ partials, long nblk, int nt,
                                                           T* __restrict__ out, int accumulate) {
+  // one workgroup per hyperparameter; fixed strided order + fixed tree => bitwise reproducible
   __shared__ T red[256];
-  for (int p = 0; p < nt; ++p) {
-    T v = T(0);
-    for (long b = threadIdx.x; b < nblk; b += 256) v += partials[b * DGP_MAX_THETA + p];
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[p] = accumulate ? out[p] + red[0] : red[0];
+  const int p = blockIdx.x;
+  T v = T(0);
+  for (long b = threadIdx.x; b < nblk; b += 256) v += partials[b * DGP_MAX_THETA + p];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
+  if (threadIdx.x == 0) out[p] = accumulate ? out[p] + red[0] : red[0];
+  (void)nt;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -364,7 +364,7 @@ int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta,
   DGP_DISPATCH_MODEL(model, d,
                      (gram_grad_kernel<T, M, 0><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), S, alpha,
                                                                                           nullptr, partials)));
-  grad_reduce_kernel<T><<<dim3(1), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0);
+  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0);
   return (int)hipGetLastError();
 }
 
@@ -379,12 +379,12 @@ int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, lo
   DGP_DISPATCH_MODEL(model, d,
                      (gram_grad_kernel<T, M, 1><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), nullptr,
                                                                                           alpha, beta, partials)));
-  grad_reduce_kernel<T><<<dim3(1), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0);
+  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0);
   dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64));
   DGP_DISPATCH_MODEL(model, d,
                      (gram_cross_grad_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xt, N, n, Xst, Mp, m, M::prepare(theta), alpha, wts,
                                                                              partials)));
-  grad_reduce_kernel<T><<<dim3(1), dim3(256), 0, s>>>(partials, (long)grid.x * grid.y, nt, dtheta, 1);
+  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, (long)grid.x * grid.y, nt, dtheta, 1);
   return (int)hipGetLastError();
 }
 
