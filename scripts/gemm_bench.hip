@@ -6,7 +6,7 @@ using namespace dgp;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <typename T, bool AKC, bool BKC, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const T* A, const T* B, T* C, long n, int ktiles) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const T* A, const T* B, T* C, long n, int ktiles) {
   using G = TileGemm<T, AKC, BKC, BM, BN>;
   __shared__ T smem[G::SMEM_ELEMS];
   const long bi = blockIdx.y, bj = blockIdx.x;
