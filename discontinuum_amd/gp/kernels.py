@@ -23,7 +23,10 @@ class Kernel(nn.Module):
 
     def __init__(self, active_dims=None, ard_num_dims=None, lengthscale_prior=None, lengthscale_constraint=None):
         super().__init__()
-        self.active_dims = None if active_dims is None else tuple(int(v) for v in active_dims)
+        if active_dims is not None:  # gpytorch registers active_dims as a buffer (it is part of state_dict)
+            self.register_buffer("active_dims", torch.as_tensor([int(v) for v in active_dims], dtype=torch.long))
+        else:
+            self.active_dims = None
         self.ard_num_dims = ard_num_dims
         self._priors = {}
         if self.has_lengthscale:

@@ -16,6 +16,11 @@ class UnsupportedKernelError(NotImplementedError):
     pass
 
 
+def _dims(k):
+    ad = getattr(k, "active_dims", None)
+    return None if ad is None else tuple(int(v) for v in ad.tolist())
+
+
 def _need(cond, what):
     if not cond:
         raise UnsupportedKernelError(f"kernel structure not supported by the HIP engine: expected {what}")
@@ -28,7 +33,7 @@ def _scale(k, what):
 
 def _matern(k, nu, dims, what, ard=None):
     _need(isinstance(k, K.MaternKernel) and k.nu == nu, f"MaternKernel(nu={nu}) for {what}")
-    _need(k.active_dims == tuple(dims), f"{what} on columns {tuple(dims)}")
+    _need(_dims(k) == tuple(int(v) for v in dims), f"{what} on columns {tuple(dims)}")
     _need(k.raw_lengthscale.shape[-1] == (ard or 1), f"{what} with {ard or 1} lengthscale(s)")
     return k
 
@@ -47,10 +52,10 @@ def _lower_loadest(cov, d):
     _need(len(parts) == 3, "seasonal + covariates + residual")
     s0, b0 = _scale(parts[0], "seasonal")
     per, m52 = _product(b0, 2, "Periodic x Matern52 on time")
-    _need(isinstance(per, K.PeriodicKernel) and per.active_dims == (0,), "PeriodicKernel on column 0")
+    _need(isinstance(per, K.PeriodicKernel) and _dims(per) == (0,), "PeriodicKernel on column 0")
     _matern(m52, 2.5, (0,), "seasonal Matern52")
     s1, rbf = _scale(parts[1], "covariates")
-    _need(isinstance(rbf, K.RBFKernel) and rbf.active_dims == tuple(range(1, d)), "ARD RBF on columns 1..d-1")
+    _need(isinstance(rbf, K.RBFKernel) and _dims(rbf) == tuple(range(1, d)), "ARD RBF on columns 1..d-1")
     _need(rbf.raw_lengthscale.shape[-1] == d - 1, "RBF with d-1 lengthscales")
     s2, m32 = _scale(parts[2], "residual")
     _matern(m32, 1.5, range(d), "residual Matern32", ard=d)
@@ -77,7 +82,7 @@ def _lower_rating(cov, d):
     sig, lw_lower = _product(parts[0], 2, "SigmoidKernel x LogWarp(lower)")
     inv, lw_upper = _product(parts[1], 2, "InvertedSigmoidKernel x LogWarp(upper)")
     lw_rest = parts[2]
-    _need(isinstance(sig, K.SigmoidKernel) and sig.active_dims == (1,) and sig.a == 20, "SigmoidKernel(a=20) on stage")
+    _need(isinstance(sig, K.SigmoidKernel) and _dims(sig) == (1,) and sig.a == 20, "SigmoidKernel(a=20) on stage")
     _need(isinstance(inv, K.InvertedSigmoidKernel) and inv.sigmoid_kernel is sig, "inverted gate sharing b")
     for lw in (lw_lower, lw_upper, lw_rest):
         _need(isinstance(lw, K.LogWarpKernel) and lw.dim == 1 and lw.eps == 1e-6, "LogWarpKernel(dim=1, eps=1e-6)")
@@ -91,7 +96,7 @@ def _lower_rating(cov, d):
     _matern(mb, 2.5, (1,), "cov_base Matern52(stage)")
     sp, bp = _scale(rest.kernels[1], "cov_periodic")
     per, pm = _product(bp, 2, "Periodic x Matern52 on time")
-    _need(isinstance(per, K.PeriodicKernel) and per.active_dims == (0,), "PeriodicKernel on column 0")
+    _need(isinstance(per, K.PeriodicKernel) and _dims(per) == (0,), "PeriodicKernel on column 0")
     _matern(pm, 2.5, (0,), "cov_periodic Matern52(time)")
 
     def theta():

@@ -19,29 +19,36 @@ class Prior(nn.Module):
         raise NotImplementedError
 
 
+def _buffers(mod, **vals):
+    """gpytorch keeps prior hyperparameters as module buffers, so they show up in ``state_dict()``
+    (e.g. ``...outputscale_prior.scale``); mirror that for checkpoint-key compatibility."""
+    for k, v in vals.items():
+        mod.register_buffer(k, torch.as_tensor(float(v), dtype=torch.float64))
+
+
 class NormalPrior(Prior):
     def __init__(self, loc, scale):
         super().__init__()
-        self.loc, self.scale = float(loc), float(scale)
+        _buffers(self, loc=loc, scale=scale)
 
     def log_prob(self, x):
-        return -0.5 * ((x - self.loc) / self.scale) ** 2 - math.log(self.scale) - 0.5 * _LOG2PI
+        return -0.5 * ((x - self.loc) / self.scale) ** 2 - torch.log(self.scale) - 0.5 * _LOG2PI
 
 
 class HalfNormalPrior(Prior):
     def __init__(self, scale):
         super().__init__()
-        self.scale = float(scale)
+        _buffers(self, scale=scale)
 
     def log_prob(self, x):
-        return math.log(2.0) - 0.5 * (x / self.scale) ** 2 - math.log(self.scale) - 0.5 * _LOG2PI
+        return math.log(2.0) - 0.5 * (x / self.scale) ** 2 - torch.log(self.scale) - 0.5 * _LOG2PI
 
 
 class GammaPrior(Prior):
     def __init__(self, concentration, rate):
         super().__init__()
-        self.concentration, self.rate = float(concentration), float(rate)
+        _buffers(self, concentration=concentration, rate=rate)
 
     def log_prob(self, x):
         a, b = self.concentration, self.rate
-        return a * math.log(b) - math.lgamma(a) + (a - 1.0) * torch.log(x) - b * x
+        return a * torch.log(b) - torch.lgamma(a) + (a - 1.0) * torch.log(x) - b * x
