@@ -208,3 +208,27 @@ def test_predictive_mean_and_vjp_fp64(model, d, n, m, gpu_device):
     assert (dtheta.cpu() - g_theta).abs().max() / g_theta.abs().max() < 1e-7
     assert (dr.cpu() - g_r).abs().max() / g_r.abs().max() < 1e-7
     assert (dnoise.cpu() - g_noise).abs().max() / g_noise.abs().max() < 1e-7
+
+
+@pytest.mark.parametrize("n", [384, 512, 640, 768, 896, 1024, 1152, 1300])
+def test_lookahead_schedule_matches_plain_schedule(n, gpu_device):
+    """Every block-column count (odd / even, with and without a final unpaired panel) through the paired
+    lookahead schedule gives the plain right-looking result (different summation order: rel 1e-12)."""
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    X, r, noise, theta = make_case("loadest", 3, n, seed=n, perturb=0.1)
+    outs = []
+    for la in (True, False):
+        p = plan_for("loadest", 3, n, X, torch.float64, dev, lookahead=la)
+        out, dr, dn = p.fit_step(theta, r.to(dev), noise.to(dev))
+        outs.append((out.cpu(), dr.cpu(), dn.cpu()))
+    (o1, a1, n1), (o2, a2, n2) = outs
+    assert o1[_lib.OUT_INFO] == 0 and o2[_lib.OUT_INFO] == 0
+    assert abs(o1[0] - o2[0]) / abs(o2[0]) < 1e-12
+    P = theta.numel()
+    assert (o1[4:4 + P] - o2[4:4 + P]).abs().max() / o2[4:4 + P].abs().max() < 1e-9
+    assert (a1 - a2).abs().max() / a2.abs().max() < 1e-9
+    val, g_theta, _, _ = orc.nll_data_and_grads("loadest", X, r, noise, theta)
+    assert abs(o1[0] - val) / abs(val) < 1e-10
+    assert (o1[4:4 + P] - g_theta).abs().max() / g_theta.abs().max() < 1e-8
