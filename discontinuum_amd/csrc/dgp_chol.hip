@@ -4,10 +4,11 @@
 // ExactMarginalLogLikelihood (src/discontinuum/engines/gpytorch.py:318, 353, 384).
 //
 //   potrf   for each 128-wide block column k:
-//             potrf_diag   one workgroup: L_kk and L_kk^-1 by an in-register Gauss-Jordan sweep
+//             potrf_diag   one workgroup: L_kk and L_kk^-1 (dgp_diag.h: LDS-blocked, wave-level pivots, MFMA)
 //             trsm         A[i,k] <- A[i,k] L_kk^-T  as an MFMA GEMM against L_kk^-1
 //             syrk         A[i,j] -= A[i,k] A[j,k]^T (MFMA), lower tiles only
-//           with a one-panel lookahead on a second HIP stream (panel k+1 overlaps update k).
+//           with a one-panel lookahead: the bulk update runs on a second HIP stream, two panels at a time
+//           (K = 256), while the panel chain of the next columns proceeds on the caller's stream.
 //   trtri   T = L^-1 by log2(N/128) levels of batched MFMA GEMMs  T21 = -T22 (L21 T11)
 //   lauum   S = T^T T = K^^-1, one launch, triangular k-range per tile
 //   solve   z = T r, quad = z^T z, alpha = T^T z (bandwidth-bound, deterministic two-stage sums)
@@ -20,211 +21,9 @@ namespace dgp {
 
 static constexpr int NB = DGP_TILE;
 
-__device__ __forceinline__ double rsqrt_nr(double d) {
-  double y = __builtin_amdgcn_rsq(d);  // v_rsq_f64 (~26 good bits) + 2 Newton steps
-  const double h = 0.5 * d;
-  double e = fma(-h * y, y, 0.5);
-  y = fma(y, e, y);
-  e = fma(-h * y, y, 0.5);
-  y = fma(y, e, y);
-  return y;
-}
-__device__ __forceinline__ float rsqrt_nr(float d) {
-  float y = __builtin_amdgcn_rsqf(d);
-  const float h = 0.5f * d;
-  float e = fmaf(-h * y, y, 0.5f);
-  y = fmaf(y, e, y);
-  return y;
-}
-
-__device__ __forceinline__ double rcp_nr(double d) {
-  double y = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + 2 Newton steps
-  double e = fma(-d, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-d, y, 1.0);
-  y = fma(y, e, y);
-  return y;
-}
-__device__ __forceinline__ float rcp_nr(float d) {
-  float y = __builtin_amdgcn_rcpf(d);
-  float e = fmaf(-d, y, 1.0f);
-  y = fmaf(y, e, y);
-  return y;
-}
-
-// ------------------------------------------------------------------------------------------
-// Diagonal block: 256 threads own the 128x128 block cyclically (thread (ti,tj) holds cells
-// (ti+16a, tj+16b), b <= a).  Step k of the sweep eliminates pivot k from the Schur complement (cells
-// right of column k) AND from the inverse being built in the cells left of it (in-place Gauss-Jordan),
-// so after 128 steps cell (i,j), j < i, holds (L_kk^-1)[i][j] / s_i with s_i = 1/sqrt(pivot_i).
-// Per step: one barrier, one LDS round trip (pivot row/column through a double-buffered 128-vector),
-// branch-free FMAs.  The reciprocal of the NEXT pivot is computed by its owner's wave only and
-// published with the vector.  Raw L columns are parked in global as they leave the registers and
-// scaled by s_k in the epilogue together with the inverse.
-template <typename T, int BS>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ A, long ld, long k0, T* __restrict__ Tinv,
-                                                         T* __restrict__ logdet, int* __restrict__ info) {
-  constexpr int NR = BS / 16;
-  __shared__ T vbuf[2][BS];
-  __shared__ T pinv[2];
-  __shared__ T dvals[BS];
-  __shared__ T svals[BS];
-  __shared__ int bad;
-  const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  T* Ablk = A + k0 * ld + k0;
-  T* Xblk = Tinv + k0 * ld + k0;
-  T reg[NR][NR];
-#pragma unroll
-  for (int a = 0; a < NR; ++a)
-#pragma unroll
-    for (int b = 0; b < NR; ++b) reg[a][b] = (b <= a) ? Ablk[(long)(ti + 16 * a) * ld + tj + 16 * b] : T(0);
-  if (tj == 0) {
-#pragma unroll
-    for (int a = 0; a < NR; ++a) vbuf[0][ti + 16 * a] = reg[a][0];
-  }
-  if (t == 0) {
-    pinv[0] = rcp_nr(reg[0][0]);
-    dvals[0] = reg[0][0];
-    bad = BS;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int kb = 0; kb < NR; ++kb) {
-#pragma unroll 1
-    for (int kt = 0; kt < 16; ++kt) {
-      const int k = kb * 16 + kt;
-      const T* v = vbuf[k & 1];
-      T* vn = vbuf[(k + 1) & 1];
-      // every LDS read of the step is issued up front, unconditionally
-      T vi[NR], vj[NR];
-#pragma unroll
-      for (int a = 0; a < NR; ++a) vi[a] = (a >= kb) ? v[ti + 16 * a] : T(0);
-#pragma unroll
-      for (int b = 0; b < NR; ++b) vj[b] = v[tj + 16 * b];
-      const T inv_d = pinv[k & 1];
-      // li = 0 on rows that are already final turns the update into unconditional FMAs
-      T li[NR];
-#pragma unroll
-      for (int a = 0; a < NR; ++a) {
-        const bool rowact = (a > kb) || (a == kb && ti > kt);
-        li[a] = rowact ? vi[a] * inv_d : T(0);
-      }
-      const bool pivcol = (tj == kt);
-      vj[kb] = pivcol ? T(1) : vj[kb];
-      const bool last = (kt == 15);
-      const int kt1 = (kt + 1) & 15;
-      // The cell that becomes the NEXT pivot is updated first and its reciprocal's Newton chain is
-      // issued unconditionally (in the same basic block), so the scheduler can hide it under the bulk
-      // FMAs below; only the owner thread's value is published.
-      const T c0 = pivcol ? T(0) : reg[kb][kb];
-      const T upd_same = fma(-li[kb], vj[kb], c0);  // cell (k+1,k+1) while it is in 16-block kb
-      const T upd_next = fma(-li[(kb + 1) % NR], vj[(kb + 1) % NR], reg[(kb + 1) % NR][(kb + 1) % NR]);
-      const T pc = last ? upd_next : upd_same;
-      const T pi = rcp_nr(pc);
-#pragma unroll
-      for (int a = 0; a < NR; ++a) {
-        if (a < kb) continue;  // rows above the pivot block are final
-#pragma unroll
-        for (int b = 0; b < NR; ++b) {
-          if (b > a) continue;
-          T cur = reg[a][b];
-          if (b == kb) cur = pivcol ? T(0) : cur;  // cell (i,k): Schur value consumed, inverse starts at 0
-          reg[a][b] = fma(-li[a], vj[b], cur);
-        }
-      }
-      if (k + 1 < BS) {
-        if (t == 17 * kt1) {
-          pinv[(k + 1) & 1] = pi;
-          dvals[k + 1] = pc;
-        }
-        // publish pivot column k+1 (rows >= k+1, also parked raw in global) and pivot row k+1 (cols <= k)
-        if (!last) {
-          if (tj == kt1) {
-#pragma unroll
-            for (int a = 0; a < NR; ++a)
-              if (a >= kb && ti + 16 * a >= k + 1) {
-                vn[ti + 16 * a] = reg[a][kb];
-                Ablk[(long)(ti + 16 * a) * ld + k + 1] = reg[a][kb];
-              }
-          }
-          if (ti == kt1) {
-#pragma unroll
-            for (int b = 0; b < NR; ++b)
-              if (b <= kb && tj + 16 * b < k + 1) vn[tj + 16 * b] = reg[kb][b];
-          }
-        } else if (kb + 1 < NR) {
-          if (tj == 0) {
-#pragma unroll
-            for (int a = 0; a < NR; ++a)
-              if (a >= kb + 1) {
-                vn[ti + 16 * a] = reg[a][(kb + 1) % NR];
-                Ablk[(long)(ti + 16 * a) * ld + k + 1] = reg[a][(kb + 1) % NR];
-              }
-          }
-          if (ti == 0) {
-#pragma unroll
-            for (int b = 0; b < NR; ++b)
-              if (b <= kb) vn[tj + 16 * b] = reg[(kb + 1) % NR][b];
-          }
-        }
-      }
-      // LDS-only barrier: __syncthreads() would also drain the parked global stores (vmcnt(0)) every step
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-  }
-  // epilogue: s_k = 1/sqrt(pivot_k); log-determinant; first bad pivot
-  __shared__ T red[BS];
-  if (t < BS) {
-    const T d = dvals[t];
-    svals[t] = rsqrt_nr(d);
-    red[t] = log(d);
-    if (!(d > T(0))) atomicMin(&bad, t);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // parked L columns have left this CU
-  __syncthreads();
-  for (int sft = BS / 2; sft > 0; sft >>= 1) {
-    if (t < sft) red[t] += red[t + sft];
-    __syncthreads();
-  }
-  if (t == 0) {
-    logdet[0] += red[0];  // diag kernels of one factorisation run in stream order
-    if (bad < BS) atomicCAS(info, 0, (int)(k0 + bad + 1));
-  }
-  // L_kk^-1 = diag(s) * cells ; L_kk = parked raw columns * s_k ; zeros above the diagonal
-#pragma unroll
-  for (int a = 0; a < NR; ++a) {
-    const int i = ti + 16 * a;
-    const T si = svals[i];
-#pragma unroll
-    for (int b = 0; b < NR; ++b) {
-      const int j = tj + 16 * b;
-      T x = T(0);
-      if (b <= a) x = j < i ? reg[a][b] * si : (j == i ? si : T(0));
-      Xblk[(long)i * ld + j] = x;
-    }
-  }
-  // all loads before any store: the compiler cannot reorder a load across a may-alias store
-  T raw[NR][NR];
-#pragma unroll
-  for (int a = 0; a < NR; ++a)
-#pragma unroll
-    for (int b = 0; b < NR; ++b) {
-      const int i = ti + 16 * a, j = tj + 16 * b;
-      raw[a][b] = (b <= a && j <= i) ? __builtin_nontemporal_load(&Ablk[(long)i * ld + j]) : T(0);  // bypasses L1
-    }
-#pragma unroll
-  for (int a = 0; a < NR; ++a)
-#pragma unroll
-    for (int b = 0; b < NR; ++b) {
-      const int i = ti + 16 * a, j = tj + 16 * b;
-      Ablk[(long)i * ld + j] = raw[a][b] * svals[j];
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // A[i,k] <- A[i,k] * L_kk^-T  (L_kk^-1 lives in the diagonal block of Tinv).  This kernel sits on the
-// sequential panel chain, so it uses 64x64 tiles: four times the workgroups, a quarter of the latency.
+// sequential panel chain, so it uses 64-row tiles: twice the workgroups, half the per-workgroup latency.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T* __restrict__ Tinv, long ld, int k) {
   // 64 rows x all 128 panel columns per workgroup: a workgroup only ever reads the rows it overwrites
