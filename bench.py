@@ -110,10 +110,17 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; DGP_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path on a
+    # single-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("DGP_BENCH_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from discontinuum_amd import _lib
     from discontinuum_amd.backend import GPPlan
