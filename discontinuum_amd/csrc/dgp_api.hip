@@ -1,6 +1,7 @@
 // dgp_api.hip -- the C ABI declared in include/dgp_hip.h: plan bookkeeping and stage sequencing.
 #include <new>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/dgp_hip.h"
@@ -64,6 +65,13 @@ static Layout layout(const dgp_plan* p) {
   return L;
 }
 
+// potrf schedule: 2 = pair-ahead lookahead (default), 1 = one-panel lookahead; DGP_LOOKAHEAD overrides (tuning only)
+static int default_lookahead() {
+  const char* e = getenv("DGP_LOOKAHEAD");
+  const int v = e ? atoi(e) : 2;
+  return v < 1 ? 1 : (v > 2 ? 2 : v);
+}
+
 extern "C" {
 
 int dgp_version(void) { return 1; }
@@ -86,7 +94,7 @@ int dgp_plan_create(int model, int dtype, int64_t n, int d, dgp_plan** out) {
   p->n = n;
   p->N = round_up(n, DGP_TILE_HOST);
   p->elem = dtype == DGP_F64 ? 8 : 4;
-  p->lookahead = 1;
+  p->lookahead = default_lookahead();
   *out = p;
   return 0;
 }
@@ -135,7 +143,7 @@ int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
 
 int dgp_plan_set_lookahead(dgp_plan* p, int enabled) {
   if (!p) return fail(DGP_E_ARG, "null plan");
-  p->lookahead = enabled ? 1 : 0;
+  p->lookahead = enabled ? default_lookahead() : 0;
   return 0;
 }
 

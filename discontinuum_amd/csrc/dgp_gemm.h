@@ -85,6 +85,39 @@ struct TileGemm {
         for (int r = 0; r < 4; ++r) acc[mi][ni][r] = T(0);
   }
 
+  // one k-tile: LDS image from the staged registers, refill them with k-tile `kt + PF`, then the MFMAs
+  template <int PF>
+  static __device__ __forceinline__ void ktile(const T* __restrict__& A, long lda, const T* __restrict__& B, long ldb,
+                                               long stepA, long stepB, int kt, int ktiles, T* __restrict__ sA,
+                                               T* __restrict__ sB, T (&ra)[OA::EPT], T (&rb)[OB::EPT],
+                                               acc_t (&acc)[MI][NI], int t, int lane, int wm, int wn) {
+    __syncthreads();  // everyone is done reading the previous k-tile's LDS image
+    OA::store(sA, ra, t);
+    OB::store(sB, rb, t);
+    __syncthreads();
+    if (kt + PF < ktiles) {  // the global loads of a later k-tile fly under this tile's MFMAs
+      OA::load(A + PF * stepA, lda, ra, t);
+      OB::load(B + PF * stepB, ldb, rb, t);
+    }
+    A += stepA;
+    B += stepB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      T fa[MI], fb[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[mi] = OA::frag(sA, wm + mi * 16, ks, lane);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fb[ni] = OB::frag(sB, wn + ni * 16, ks, lane);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::mma(fa[mi], fb[ni], acc[mi][ni]);
+    }
+  }
+
+  // PF = number of k-tiles the global loads run ahead of the MFMAs (register-staged).  PF = 2 costs one more
+  // set of staging registers and pays where the operands miss L2 (long, unsynchronised k-ranges: lauum / trtri).
+  template <int PF = 1>
   static __device__ __forceinline__ void run(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb,
                                              int ktiles, T* __restrict__ smem, acc_t (&acc)[MI][NI]) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -93,34 +126,18 @@ struct TileGemm {
     T* sB = smem + OA::ELEMS;
     const long stepA = A_KC ? 16 : 16 * lda;
     const long stepB = B_KC ? 16 : 16 * ldb;
-    T ra[OA::EPT], rb[OB::EPT];
-    if (ktiles > 0) {
-      OA::load(A, lda, ra, t);
-      OB::load(B, ldb, rb, t);
-    }
-    for (int kt = 0; kt < ktiles; ++kt) {
-      __syncthreads();  // everyone is done reading the previous k-tile's LDS image
-      OA::store(sA, ra, t);
-      OB::store(sB, rb, t);
-      __syncthreads();
-      if (kt + 1 < ktiles) {  // next k-tile's global loads fly under this tile's MFMAs
-        A += stepA;
-        B += stepB;
-        OA::load(A, lda, ra, t);
-        OB::load(B, ldb, rb, t);
+    T ra[PF][OA::EPT], rb[PF][OB::EPT];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (p < ktiles) {
+        OA::load(A + p * stepA, lda, ra[p], t);
+        OB::load(B + p * stepB, ldb, rb[p], t);
       }
+    for (int kt = 0; kt < ktiles; kt += PF) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        T fa[MI], fb[NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fa[mi] = OA::frag(sA, wm + mi * 16, ks, lane);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) fb[ni] = OB::frag(sB, wn + ni * 16, ks, lane);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mfma<T>::mma(fa[mi], fb[ni], acc[mi][ni]);
-      }
+      for (int p = 0; p < PF; ++p)
+        if (kt + p < ktiles)
+          ktile<PF>(A, lda, B, ldb, stepA, stepB, kt + p, ktiles, sA, sB, ra[p], rb[p], acc, t, lane, wm, wn);
     }
   }
 

@@ -80,6 +80,10 @@ int main() {
   bench_syrk<double, 1>("f64 syrk store-only K=128", 8192, 128);
   bench_syrk<double, 0>("f64 syrk RMW K=256", 8192, 256);
   bench_syrk<double, 0>("f64 syrk RMW K=512", 8192, 512);
+  bench_syrk<double, 0>("f64 syrk RMW K=1024", 8192, 1024);
+  bench_syrk<double, 0>("f64 syrk RMW K=2048", 8192, 2048);
+  bench_syrk<double, 1>("f64 syrk store-only K=256", 8192, 256);
+  bench_syrk<double, 1>("f64 syrk store-only K=1024", 8192, 1024);
   bench_syrk<double, 0>("f64 syrk RMW K=128 n=4096", 4096, 128);
 
   const long n = 8192;
