@@ -16,6 +16,8 @@ Differences from the reference, on purpose:
 """
 from __future__ import annotations
 
+import math
+
 from dataclasses import dataclass
 
 import numpy as np
@@ -209,9 +211,11 @@ class MarginalHIP(BaseModel):
         lr_choice = learning_rate if learning_rate is not None else (saved_lr or 0.05)
         params = list(self.model.parameters())
         if opt_choice == "adamw" or (saved_name and saved_name.lower() == "adamw"):
-            optimizer_obj = torch.optim.AdamW(params, lr=lr_choice, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+            optimizer_obj = torch.optim.AdamW(params, lr=lr_choice, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                                              foreach=True)
         elif opt_choice == "adam" or (saved_name and saved_name.lower() == "adam"):
-            optimizer_obj = torch.optim.Adam(params, lr=lr_choice, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+            optimizer_obj = torch.optim.Adam(params, lr=lr_choice, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
+                                             foreach=True)  # same update rule, one multi-tensor call per step
         else:
             raise ValueError(f"Unsupported optimizer: {opt_choice!r}. Supported optimizers are 'adam' and 'adamw'.")
         if can_restore and resume_info.get("optimizer_state_dict") is not None:
@@ -285,8 +289,10 @@ class MarginalHIP(BaseModel):
                     continue
                 nan_loss_counter = 0
                 objective.backward()
-                torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
-                has_nan_grad = any(p.grad is not None and torch.isnan(p.grad).any() for p in params)
+                total_norm = torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+                # the reference scans every p.grad for NaN after clipping (engines/gpytorch.py:387-392); a clipped
+                # gradient holds a NaN exactly when the pre-clip norm is NaN or Inf (Inf * 0 = NaN), so one scalar says it
+                has_nan_grad = not math.isfinite(float(total_norm))
                 if has_nan_grad:
                     for p in params:
                         if p.grad is not None:

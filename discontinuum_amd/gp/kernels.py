@@ -59,6 +59,12 @@ def named_priors(module: nn.Module):
             yield (f"{mod_name}.{name}" if mod_name else name), prior, closure(mod)
 
 
+def prior_closures(module: nn.Module):
+    """[(prior, closure, owner module)] for every registered prior: the walk of ``named_priors`` done once."""
+    return [(prior, closure, mod) for _n, mod in module.named_modules()
+            for prior, closure in getattr(mod, "_priors", {}).values()]
+
+
 class RBFKernel(Kernel):
     has_lengthscale = True
 
@@ -166,5 +172,5 @@ class LogWarpKernel(Kernel):
 
 __all__ = [
     "Kernel", "RBFKernel", "MaternKernel", "PeriodicKernel", "ScaleKernel", "AdditiveKernel", "ProductKernel",
-    "SigmoidKernel", "InvertedSigmoidKernel", "LogWarpKernel", "Interval", "Positive", "named_priors",
+    "SigmoidKernel", "InvertedSigmoidKernel", "LogWarpKernel", "Interval", "Positive", "named_priors", "prior_closures",
 ]

@@ -16,7 +16,7 @@ import warnings
 import torch
 
 from .. import _lib
-from .kernels import named_priors
+from .kernels import prior_closures
 
 
 class NotPSDError(RuntimeError):
@@ -27,8 +27,9 @@ class _ExactGPNLL(torch.autograd.Function):
     """nll_data(theta, r, noise) = 1/2 r^T K^^-1 r + 1/2 log|K^| + n/2 log 2 pi, K^ = K(theta) + diag(noise)."""
 
     @staticmethod
-    def forward(ctx, plan, theta, r, noise):
-        out, dr, dnoise = plan.fit_step(theta, r, noise)
+    def forward(ctx, plan, theta, r, noise, pending=None):
+        # `pending` = the (out, dr, dnoise) of a fit_step already launched with these arguments
+        out, dr, dnoise = pending if pending is not None else plan.fit_step(theta, r, noise)
         host = out.to("cpu", torch.float64)  # the one device->host sync of a fit step
         info = int(host[_lib.OUT_INFO].item())
         if info != 0:
@@ -41,7 +42,7 @@ class _ExactGPNLL(torch.autograd.Function):
     def backward(ctx, g):
         dtheta, dr, dnoise = ctx.saved_tensors
         gd = g.to(dr.device, dr.dtype)
-        return None, (dtheta * g).to(ctx.theta_dtype), dr * gd, dnoise * gd
+        return None, (dtheta * g).to(ctx.theta_dtype), dr * gd, dnoise * gd, None
 
 
 class _PredictiveMean(torch.autograd.Function):
@@ -67,11 +68,11 @@ def predictive_mean(plan, theta, r, noise, Xs):
     return _PredictiveMean.apply(plan, theta, r, noise, Xs)
 
 
-def exact_gp_nll(plan, theta, r, noise):
+def exact_gp_nll(plan, theta, r, noise, pending=None):
     """Differentiable data term with gpytorch's jitter-retry policy. Returns a 0-dim CPU float64 tensor."""
     jitter0 = 1e-8 if plan.dtype == torch.float64 else 1e-6
     try:
-        return _ExactGPNLL.apply(plan, theta, r, noise)
+        return _ExactGPNLL.apply(plan, theta, r, noise, pending)
     except NotPSDError:
         for i in range(3):
             jitter = jitter0 * 10 ** i
@@ -88,19 +89,23 @@ class ExactMarginalLogLikelihood:
     def __init__(self, likelihood, model):
         self.likelihood = likelihood
         self.model = model
+        # the module tree is fixed for the lifetime of an mll object (one fit): walk it once
+        self._priors = prior_closures(model)
+        if likelihood is not None and not any(likelihood is m for m in model.modules()):
+            self._priors += prior_closures(likelihood)
 
     def log_prior(self):
         lp = torch.zeros((), dtype=torch.float64)
-        for _name, prior, value in named_priors(self.model):
-            lp = lp + prior.log_prob(value).sum()
-        if self.likelihood is not None and not any(self.likelihood is m for m in self.model.modules()):
-            for _name, prior, value in named_priors(self.likelihood):
-                lp = lp + prior.log_prob(value).sum()
+        for prior, closure, mod in self._priors:
+            lp = lp + prior.log_prob(closure(mod)).sum()
         return lp
 
     def __call__(self, output, target):
         """``output`` is the engine's prior spec (plan, theta, mean on device, noise on device)."""
         n = target.shape[0]
         r = (target - output.mean).contiguous()
-        nll = exact_gp_nll(output.plan, output.theta, r, output.noise.contiguous())
-        return ((-nll + self.log_prior()) / n).reshape(1)  # shape (1,) like the reference's (1, n)-noise batch
+        noise = output.noise.contiguous()
+        pending = output.plan.fit_step(output.theta, r, noise)  # asynchronous: the device starts now ...
+        lp = self.log_prior()                                   # ... and the O(P) host algebra runs under it
+        nll = exact_gp_nll(output.plan, output.theta, r, noise, pending)
+        return ((-nll + lp) / n).reshape(1)  # shape (1,) like the reference's (1, n)-noise batch
