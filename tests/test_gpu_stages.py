@@ -232,3 +232,61 @@ def test_lookahead_schedule_matches_plain_schedule(n, gpu_device):
     val, g_theta, _, _ = orc.nll_data_and_grads("loadest", X, r, noise, theta)
     assert abs(o1[0] - val) / abs(val) < 1e-10
     assert (o1[4:4 + P] - g_theta).abs().max() / g_theta.abs().max() < 1e-8
+
+
+@pytest.mark.parametrize("model,d,n", [("loadest", 2, 1), ("loadest", 2, 2), ("loadest", 3, 17), ("loadest", 2, 127),
+                                       ("loadest", 3, 128), ("loadest", 2, 129), ("rating", 2, 3), ("rating", 2, 257)])
+def test_edge_sizes_fp64(model, d, n, gpu_device):
+    """Sizes at and around the 128-wide padding quantum, down to a single observation."""
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=11, perturb=0.1)
+    r = torch.nan_to_num(r, nan=0.3)  # the generator standardises y: undefined for a single observation
+    val, g_theta, g_r, g_noise = orc.nll_data_and_grads(model, X, r, noise, theta)
+    p = plan_for(model, d, n, X, torch.float64, dev)
+    out, alpha, dnoise = p.fit_step(theta, r.to(dev), noise.to(dev))
+    out = out.cpu()
+    assert int(out[3]) == 0
+    assert abs(out[0].item() - val.item()) <= 1e-10 * max(1.0, abs(val.item()))
+    gt = out[4:4 + p.ntheta]
+    assert (gt - g_theta).abs().max() <= 1e-8 * max(1.0, g_theta.abs().max().item())
+    assert (alpha.cpu() - g_r).abs().max() <= 1e-8 * max(1.0, g_r.abs().max().item())
+    assert (dnoise.cpu() - g_noise).abs().max() <= 1e-8 * max(1.0, g_noise.abs().max().item())
+    # a single prediction point, and more prediction points than observations
+    for m in (1, 2 * n + 3):
+        Xs, *_ = make_case(model, d, m, seed=12)
+        mu_ref, var_ref = orc.posterior(model, X, r, noise, theta, Xs)
+        mu, var = p.predict(theta, Xs.to(dev))
+        assert (mu.cpu() - mu_ref).abs().max() < 1e-9
+        assert ((var.cpu() - var_ref).abs() / (var_ref.abs() + 1e-4)).max() < 1e-8
+
+
+def test_repeated_observations_fp64(gpu_device):
+    """Identical input rows (collisions): K is singular, K + Sigma is not -- the factorisation must go through."""
+    dev = gpu_device
+    X, r, noise, theta = make_case("loadest", 3, 300, seed=2, perturb=0.1)
+    X = torch.cat([X[:150], X[:150]])  # every row twice
+    val, g_theta, g_r, _ = orc.nll_data_and_grads("loadest", X, r, noise, theta)
+    p = plan_for("loadest", 3, 300, X, torch.float64, dev)
+    out, alpha, _ = p.fit_step(theta, r.to(dev), noise.to(dev))
+    out = out.cpu()
+    assert int(out[3]) == 0
+    assert abs(out[0].item() - val.item()) <= 1e-9 * abs(val.item())
+    assert (out[4:4 + p.ntheta] - g_theta).abs().max() <= 1e-7 * max(1.0, g_theta.abs().max().item())
+    assert (alpha.cpu() - g_r).abs().max() <= 1e-7 * max(1.0, g_r.abs().max().item())
+
+
+def test_nan_input_is_reported_not_hidden(gpu_device):
+    """A NaN in the residual or the inputs must surface in the outputs (NaN NLL or non-zero info), never a finite lie."""
+    dev = gpu_device
+    X, r, noise, theta = make_case("loadest", 2, 200, seed=3)
+    p = plan_for("loadest", 2, 200, X, torch.float64, dev)
+    r_bad = r.clone()
+    r_bad[7] = float("nan")
+    out, *_ = p.fit_step(theta, r_bad.to(dev), noise.to(dev))
+    assert not np.isfinite(out.cpu()[0].item())
+    X_bad = X.clone()
+    X_bad[5, 0] = float("nan")
+    p.set_inputs(X_bad.to(dev).contiguous())
+    out, *_ = p.fit_step(theta, r.to(dev), noise.to(dev))
+    out = out.cpu()
+    assert (not np.isfinite(out[0].item())) or int(out[3]) != 0
