@@ -47,9 +47,8 @@ def synth_loadest(n, d, seed):
     return np.concatenate([t[:, None], cov], axis=1), y
 
 
-def cpu_baseline(n, d, dtype_name, budget_s=75.0):
-    """Time the oracle's NLL + gradient step on the host.  Probe at n=2048, then run the largest
-    n <= target whose cubic extrapolation fits the budget."""
+def cpu_baseline(n, d, dtype_name):
+    """Time one NLL + gradient step of the oracle on the host (test infrastructure used as the CPU baseline)."""
     from oracle import gp_oracle as orc
 
     # the GPU box exposes many more hardware threads than the job's CPU share; oversubscribing torch's
@@ -70,13 +69,11 @@ def cpu_baseline(n, d, dtype_name, budget_s=75.0):
         orc.nll_data_and_grads("loadest", X, y, noise, theta)
         return time.perf_counter() - t0
 
-    probe_n = min(2048, n)
+    # one step at the metric's own n = 8192 costs ~14 s on the GPU box's host share (the bounded sample the
+    # contract asks for); only larger n are sampled at 8192 and scaled by the cubic flop count
     one(min(512, n))  # warm the thread pool / allocator
-    t_probe = one(probe_n)
-    ns = n
-    while ns > probe_n and t_probe * (ns / probe_n) ** 3 > budget_s:
-        ns //= 2
-    t_s = t_probe if ns == probe_n else one(ns)
+    ns = min(n, 8192)
+    t_s = one(ns)
     fits = 1.0 / t_s
     scaled = fits * (ns / n) ** 3
     sample = (f"1 NLL+grad step of oracle/gp_oracle.py (torch CPU fp64 dense, autograd) at n={ns} d={d}, "
@@ -134,7 +131,9 @@ def main():
     plans, streams, ys = [], [], []
     for sidx in range(S):  # S independent sites per rank, each with its own plan and stream
         X, y = synth_loadest(n, d, seed=rank * S + sidx)
-        p = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=not args.no_lookahead)
+        # several plans in flight on one GPU: level 1 (their stages fill each other's idle CUs); the single-site
+        # plan below uses the default level 2 (early inverse on a third stream)
+        p = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=0 if args.no_lookahead else (1 if S > 1 else 2))
         p.set_inputs(torch.tensor(X, dtype=dt, device=dev).contiguous())
         plans.append(p)
         ys.append(torch.tensor(y, dtype=dt, device=dev).contiguous())
@@ -177,7 +176,9 @@ def main():
     # ---- single-site loop on rank 0: latency of one fit alone on the GPU + per-kernel HIP-event timings
     single_ms = None
     if rank == 0:
-        plan.set_timing(True)
+        level = 0 if args.no_lookahead else (1 if S > 1 else 2)  # what the timed region above ran with
+        if not args.no_lookahead:
+            plan.set_lookahead(2)  # alone on the GPU: also issue the inverse early (third stream)
         ksingle = max(3, args.steps // 2)
         plan.fit_step(theta, ys[0], noise)
         torch.cuda.synchronize()
@@ -186,6 +187,13 @@ def main():
             plan.fit_step(theta, ys[0], noise)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / ksingle * 1e3
+        # per-kernel HIP-event timings for the roofline: same schedule as the timed region, one site at a time
+        # (the events bracket every bulk launch on the stream it runs on; the last step is reported)
+        plan.set_lookahead(level)
+        plan.set_timing(True)
+        for _ in range(3):
+            plan.fit_step(theta, ys[0], noise)
+        torch.cuda.synchronize()
 
     if rank == 0:
         N = plan.N
@@ -198,8 +206,10 @@ def main():
             "trtri_level_kernel": {"flops": N ** 3 / 3.0, "ms": ms[_lib.TIME_TRTRI], "launches": None},
             "lauum_kernel": {"flops": N ** 3 / 3.0, "ms": ms[_lib.TIME_LAUUM], "launches": 1},
         }
+        if level == 2:  # most of the inverse ran under the factorisation: its stage time is only the remainder
+            stages["trtri_level_kernel"]["flops"] = None
         for v in stages.values():
-            v["tflops"] = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None
+            v["tflops"] = v["flops"] / (v["ms"] * 1e-3) / 1e12 if (v["flops"] and v["ms"] > 0) else None
         dom = max(stages, key=lambda k: stages[k]["ms"])
         ach = stages[dom]["tflops"]
         gram_bytes = N * (N + 64) / 2 * esz + n * d * esz
@@ -224,7 +234,7 @@ def main():
                           "trtri": ms[_lib.TIME_TRTRI], "lauum": ms[_lib.TIME_LAUUM], "solve": ms[_lib.TIME_SOLVE],
                           "grad": ms[_lib.TIME_GRAD]},
             "fit_flops": float(N) ** 3, "job_tflops": float(N) ** 3 * world * S * args.steps / elapsed / 1e12,
-            "measured_in": "single-site loop (one fit at a time on the GPU), last step",
+            "measured_in": "one site at a time on the GPU with the timed region's schedule (lookahead level %d), last of 3 steps" % level,
             "gram_hbm": {"bound": "hbm", "achieved": gram_bytes / (ms[_lib.TIME_GRAM] * 1e-3) / 1e9 if ms[_lib.TIME_GRAM] > 0 else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes": gram_bytes},
         }

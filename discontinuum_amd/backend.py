@@ -38,6 +38,8 @@ class GPPlan:
     """Fixed (model, dtype, n, d) exact-GP problem resident on one GPU."""
 
     def __init__(self, model: str, n: int, d: int, dtype=torch.float64, device="cuda", lookahead=True):
+        """``lookahead``: False / 0 = one stream; 1 = bulk updates beside the panel chain (use this when several
+        plans share one GPU); True / 2 = also the early inverse on a third stream (best for one plan per GPU)."""
         if model not in MODELS:
             raise ValueError(f"unknown model {model!r}; expected one of {sorted(MODELS)}")
         if dtype not in _DTYPES:
@@ -77,8 +79,9 @@ class GPPlan:
             self._h = None
 
     # ------------------------------------------------------------------ helpers
-    def set_lookahead(self, enabled: bool):
-        _lib.check(self.lib.dgp_plan_set_lookahead(self._h, int(bool(enabled))), "dgp_plan_set_lookahead")
+    def set_lookahead(self, level):
+        level = 2 if level is True else int(level)
+        _lib.check(self.lib.dgp_plan_set_lookahead(self._h, level), "dgp_plan_set_lookahead")
 
     def _check_vec(self, t, name, length=None):
         length = self.n if length is None else length

@@ -13,6 +13,8 @@
 //   lauum   S = T^T T = K^^-1, one launch, triangular k-range per tile
 //   solve   z = T r, quad = z^T z, alpha = T^T z (bandwidth-bound, deterministic two-stage sums)
 // Flops per fit: N^3/3 (potrf) + N^3/3 (trtri) + N^3/3 (lauum) -- MFMA roofline.
+#include <string.h>
+#include <mutex>
 #include "dgp_diag.h"
 #include "dgp_gemm.h"
 #include "dgp_internal.h"
@@ -20,6 +22,7 @@
 namespace dgp {
 
 static constexpr int NB = DGP_TILE;
+static constexpr int SMID_TABLE = 4096;  // covers the XCC | SE | CU id bits of __smid()
 // k-tiles of register prefetch (TileGemm::run<PF>) for the kernels whose operands mostly miss L2
 // (measured at n = 8192: fp64 lauum 2.99 -> 2.87 ms with 2; fp64 trtri gets SLOWER with 2 -- 256 VGPRs; fp32 has room)
 template <typename T>
@@ -83,8 +86,11 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, lon
 
 template <typename T>
 __global__ void zero1_kernel(T* p, int* info) {
-  p[0] = T(0);
-  info[0] = 0;
+  if (threadIdx.x == 0) {
+    p[0] = T(0);
+    info[0] = 0;
+  }
+  for (int i = threadIdx.x; i < 2 * EARLY_CTR_PAIRS; i += blockDim.x) info[EARLY_CTR0 + i] = 0;  // early-launch queues
 }
 
 // launch the LDS-resident diagonal-block kernel (needs > 64 KB of dynamic LDS: opt in once per type)
@@ -102,11 +108,22 @@ static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hi
 
 template <typename T>
 int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
-          hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop) {
+          hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop, int nck, const int* ck_blocks, hipEvent_t* ck_ev,
+          void (*on_ck)(void*, int), void* ck_ctx) {
   const int nbk = (int)(N / NB);
+  // checkpoint c: recorded on s once the first ck_blocks[c] block columns of L are final (every schedule records
+  // every checkpoint, at the latest when the factorisation is complete)
+  int ck_next = 0;
+  auto checkpoint = [&](int cols_final) {
+    while (ck_next < nck && ck_blocks[ck_next] <= cols_final) {
+      hipEventRecord(ck_ev[ck_next], s);
+      if (on_ck) on_ck(ck_ctx, ck_next);  // the caller enqueues its dependent work NOW, not after the whole schedule
+      ++ck_next;
+    }
+  };
   int ns = 0;
   double flop = 0.0;
-  zero1_kernel<T><<<1, 1, 0, s>>>(logdet, info);
+  zero1_kernel<T><<<1, 64, 0, s>>>(logdet, info);
   auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
   const double tile_flop = 2.0 * NB * NB * NB;
   if (!lookahead || nbk < 4 || s2 == nullptr || ev == nullptr) {
@@ -121,6 +138,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         ++ns;
       }
     }
+    checkpoint(nbk);
     if (n_syrk) *n_syrk = ns;
     if (syrk_flop) *syrk_flop = flop;
     return (int)hipGetLastError();
@@ -145,6 +163,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         if (nk > 0) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2), 256, 0, s>>>(A, N, kfirst, nk, k);
         launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s);
         if (k + 1 < nbk) trsm_kernel<T><<<2 * (nbk - k - 1), 256, 0, s>>>(A, Tinv, N, k);
+        checkpoint(k + 1);
       }
       if (2 * q + 4 < nbk) {
         hipEventRecord(P[q], s);
@@ -158,6 +177,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
       }
     }
     // bulk(q) exists for q <= Q-3 and chain(q+2) has waited on every one of them: s is joined
+    checkpoint(nbk);
     if (n_syrk) *n_syrk = ns;
     if (syrk_flop) *syrk_flop = flop;
     return (int)hipGetLastError();
@@ -205,6 +225,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     const int last_pair = kmax >= 1 ? (kmax - 1) / 2 : -1;
     if (last_pair >= 0 && last_u < last_pair) hipStreamWaitEvent(s, U[last_pair], 0);
   }
+  checkpoint(nbk);
   if (n_syrk) *n_syrk = ns;
   if (syrk_flop) *syrk_flop = flop;
   return (int)hipGetLastError();
@@ -217,49 +238,198 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
 // BT = 128 for the large levels; the small levels (few tiles, short k) use 64x64 tiles so that four
 // times as many workgroups share the work.
 template <typename T, int STEP, int BT>
-__global__ __launch_bounds__(256, 2) void trtri_level_kernel(const T* __restrict__ L, T* __restrict__ Tm,
-                                                             T* __restrict__ W, long ld, int m, int ntile) {
+__device__ __forceinline__ void trtri_tile(const T* __restrict__ L, T* __restrict__ Tm, T* __restrict__ W, long ld,
+                                           int m, int lo, int mid, int hi, int tile, T* __restrict__ smem) {
   using G = TileGemm<T, true, false, BT, BT>;
-  __shared__ T smem[G::SMEM_ELEMS];
-  const int lo = 2 * m * blockIdx.y, mid = lo + m, hi = min(lo + 2 * m, ntile);
+  constexpr int KT = BT / 16;  // k-tiles per tile of the reduction dimension
   // longest k-range first: W-step K ~ (mid - j), T-step K ~ (i - mid + 1)
-  const int i = STEP == 0 ? mid + blockIdx.x % m : mid + (m - 1 - blockIdx.x / m);
-  const int j = STEP == 0 ? lo + blockIdx.x / m : lo + blockIdx.x % m;
+  const int i = STEP == 0 ? mid + tile % m : mid + (m - 1 - tile / m);
+  const int j = STEP == 0 ? lo + tile / m : lo + tile % m;
   if (i >= hi) return;
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
-  constexpr int KT = BT / 16;  // k-tiles per tile of the reduction dimension
   if (STEP == 0) {
     G::template run<Prefetch<T>::TRTRI>(L + (long)i * BT * ld + (long)j * BT, ld, Tm + (long)j * BT * ld + (long)j * BT, ld,
-                              (mid - j) * KT, smem, acc);
+                                        (mid - j) * KT, smem, acc);
     T* out = W + (long)i * BT * ld + (long)j * BT;
     G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
   } else {
-    G::template run<Prefetch<T>::TRTRI>(Tm + (long)i * BT * ld + (long)mid * BT, ld, W + (long)mid * BT * ld + (long)j * BT, ld,
-                              (i - mid + 1) * KT, smem, acc);
+    G::template run<Prefetch<T>::TRTRI>(Tm + (long)i * BT * ld + (long)mid * BT, ld, W + (long)mid * BT * ld + (long)j * BT,
+                                        ld, (i - mid + 1) * KT, smem, acc);
     T* out = Tm + (long)i * BT * ld + (long)j * BT;
     G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = -v; });
   }
 }
 
-template <typename T, int BT>
-static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, hipStream_t s) {
-  const int per = NB / BT;                   // tiles per 128-block
-  const int m = mblk * per, ntile = (int)(N / BT);
-  const int ngroups = (ntile + 2 * m - 1) / (2 * m);
-  dim3 grid((unsigned)(m * m), (unsigned)ngroups);
-  trtri_level_kernel<T, 0, BT><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile);
-  trtri_level_kernel<T, 1, BT><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile);
+// QUEUE = false: one workgroup per tile.
+// QUEUE = true: the EARLY launches that share the GPU with the factorisation's panel chain.  Few persistent
+// workgroups (about one per CU) pull (group, tile) pairs from a queue (ctr[0]); a workgroup that finds itself on a
+// RESERVED compute unit (table indexed by the hardware CU id) leaves at once, so those CUs stay free for the
+// latency-critical chain kernels -- co-resident GEMM waves slow the diagonal-block kernel 2-5x.  Correctness does
+// not depend on where workgroups land: a reserved-CU workgroup only leaves once some other workgroup has
+// announced (ctr[1]) that it will drain the queue; until then it works like any other.
+template <typename T, int STEP, int BT, bool QUEUE>
+__global__ __launch_bounds__(256, 2) void trtri_level_kernel(const T* __restrict__ L, T* __restrict__ Tm,
+                                                             T* __restrict__ W, long ld, int m, int ntile, int g0,
+                                                             int ngroups, int* __restrict__ ctr,
+                                                             const unsigned char* __restrict__ resv) {
+  using G = TileGemm<T, true, false, BT, BT>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  if (!QUEUE) {
+    const int lo = 2 * m * (g0 + (int)blockIdx.y), mid = lo + m, hi = min(lo + 2 * m, ntile);
+    trtri_tile<T, STEP, BT>(L, Tm, W, ld, m, lo, mid, hi, (int)blockIdx.x, smem);
+  } else {
+    __shared__ int next_item;
+    const int nitems = m * m * ngroups;
+    const bool on_reserved = resv != nullptr && resv[__smid() & (SMID_TABLE - 1)] != 0;
+    if (threadIdx.x == 0 && !on_reserved) atomicAdd(&ctr[1], 1);
+#pragma unroll 1
+    for (;;) {
+      if (threadIdx.x == 0) {
+        int it = nitems;
+        if (!on_reserved || __hip_atomic_load(&ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+          it = atomicAdd(&ctr[0], 1);
+        next_item = it;
+      }
+      __syncthreads();
+      const int it = __builtin_amdgcn_readfirstlane(next_item);
+      __syncthreads();
+      if (it >= nitems) return;  // every workgroup gets here once the queue is empty
+      const int g = it % ngroups, tile = it / ngroups;  // tile-major: the long-k tiles of every group first
+      const int lo = 2 * m * (g0 + g), mid = lo + m, hi = min(lo + 2 * m, ntile);
+      trtri_tile<T, STEP, BT>(L, Tm, W, ld, m, lo, mid, hi, tile, smem);
+    }
+  }
+}
+
+// ---- reserved compute units ------------------------------------------------------------------
+// A probe launch lists the hardware ids (__smid: XCC | SE | CU) of the CUs this process can use; every
+// (count / nreserve)-th one, in id order, is marked in a small per-device table (spread over XCDs and SEs).
+__global__ void smid_probe_kernel(unsigned* out) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 2000) __builtin_amdgcn_s_sleep(8);  // ~20 us: long enough to fill every CU
+  if (threadIdx.x == 0) out[blockIdx.x] = __smid();
+}
+
+const unsigned char* reserved_cu_table(int nreserve, int* n_cu) {
+  struct Entry {
+    int built;
+    unsigned char* table;
+    int ncu, nres;
+  };
+  static Entry cache[64];
+  static std::mutex mtx;  // plans on several host threads may reach their first fit together
+  std::lock_guard<std::mutex> lock(mtx);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  Entry& e = cache[dev];
+  if (!e.built) {
+    e.built = 1;
+    const int nprobe = 8192;
+    unsigned* d = nullptr;
+    if (hipMalloc(&d, nprobe * sizeof(unsigned)) != hipSuccess) return nullptr;
+    smid_probe_kernel<<<nprobe, 64>>>(d);
+    unsigned* h = new unsigned[nprobe];
+    const bool ok = hipMemcpy(h, d, nprobe * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    unsigned char host[SMID_TABLE];
+    memset(host, 0, sizeof(host));
+    int ncu = 0;
+    if (ok)
+      for (int i = 0; i < nprobe; ++i)
+        if (h[i] < (unsigned)SMID_TABLE && !host[h[i]]) {
+          host[h[i]] = 1;
+          ++ncu;
+        }
+    delete[] h;
+    e.ncu = ncu;
+    if (nreserve > 0 && ncu >= 2 * nreserve) {
+      const int stride = ncu / nreserve;
+      int rank = 0, nres = 0;
+      for (int id = 0; id < SMID_TABLE; ++id) {
+        if (!host[id]) continue;
+        host[id] = (rank % stride == stride / 2 && nres < nreserve) ? 2 : 1;
+        nres += host[id] == 2;
+        ++rank;
+      }
+      for (int id = 0; id < SMID_TABLE; ++id) host[id] = host[id] == 2;
+      e.nres = nres;
+      if (hipMalloc(&e.table, SMID_TABLE) != hipSuccess ||
+          hipMemcpy(e.table, host, SMID_TABLE, hipMemcpyHostToDevice) != hipSuccess)
+        e.table = nullptr;
+    }
+  }
+  if (n_cu) *n_cu = e.ncu;
+  return e.table;
+}
+
+// groups [g0, g1) of the level with half-size mblk (in 128-blocks), one step
+// `early` != null: queue-driven launch of at most early->wg_cap workgroups that keeps the reserved CUs free
+struct EarlyLaunch {
+  int wg_cap;
+  int* ctr;                   // next free (queue, workers) counter pair, zeroed at the start of the factorisation
+  int pairs_left;
+  const unsigned char* resv;  // reserved-CU table or null
+};
+
+template <typename T, int STEP>
+static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g1, EarlyLaunch* early, hipStream_t s) {
+  if (g1 <= g0) return;
+  const int ng = g1 - g0;
+  // <= 512 tiles of 128^2 would leave the GPU waiting on the longest one: the small levels use 64^2 tiles
+  const bool small = mblk <= 16;
+  const int m = small ? 2 * mblk : mblk, ntile = (int)(N / (small ? 64 : 128));
+  const bool queue = early != nullptr && early->pairs_left > 0 && m * m * ng > early->wg_cap;
+  if (!queue) {
+    const dim3 grid((unsigned)(m * m), (unsigned)ng);
+    if (small) trtri_level_kernel<T, STEP, 64, false><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, nullptr, nullptr);
+    else trtri_level_kernel<T, STEP, 128, false><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, nullptr, nullptr);
+    return;
+  }
+  int* ctr = early->ctr;
+  early->ctr += 2;
+  --early->pairs_left;
+  const unsigned grid = (unsigned)early->wg_cap;
+  if (small) trtri_level_kernel<T, STEP, 64, true><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, ctr, early->resv);
+  else trtri_level_kernel<T, STEP, 128, true><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, ctr, early->resv);
+}
+
+// Launch every step of the level recursion that the first `ready` block columns of L (and the diagonal blocks
+// of T that the factorisation wrote with them) allow and that `st` has not seen yet.  A group [lo, hi) split
+// at mid needs hi <= ready for its T-step, but only mid <= ready for its W-step (W = L21 T11 reads columns
+// < mid of L, which are final for ALL rows once their panels are): so while the factorisation is still
+// working down its sequential tail, most of the inverse's GEMM work can already run on the idle CUs.
+// All launches of one TrtriProgress must go to the same stream (level order = stream order).  wg_cap > 0 limits
+// the workgroups per launch (persistent, queue-driven, see trtri_level_kernel): early launches share the GPU with
+// the panel chain; `ctr` = nctr_pairs zeroed (queue, workers) int pairs, `reserve_cus` CUs are left to the chain.
+template <typename T>
+int trtri_advance(const T* L, long N, T* Tm, T* W, int ready, TrtriProgress* st, hipStream_t s, int wg_cap, int* ctr,
+                  int nctr_pairs, int reserve_cus) {
+  const int nbk = (int)(N / NB);
+  if (ready > nbk) ready = nbk;
+  EarlyLaunch el{wg_cap, ctr + 2 * st->pairs_used, nctr_pairs - st->pairs_used,
+                 reserve_cus > 0 ? reserved_cu_table(reserve_cus, nullptr) : nullptr};
+  EarlyLaunch* early = (wg_cap > 0 && ctr != nullptr) ? &el : nullptr;
+  int lvl = 0;
+  for (int m = 1; m < nbk && lvl < TrtriProgress::MAXLVL; m *= 2, ++lvl) {
+    const int ngroups = (nbk + 2 * m - 1) / (2 * m);
+    int full = 0;  // groups whose whole range [lo, hi) is final
+    while (full < ngroups && (2 * m * (full + 1) < nbk ? 2 * m * (full + 1) : nbk) <= ready) ++full;
+    int wcan = full;  // groups whose W-step can run
+    if (wcan < ngroups && 2 * m * wcan + m <= ready) ++wcan;
+    trtri_level<T, 0>(L, Tm, W, N, m, st->wdone[lvl], wcan, early, s);
+    trtri_level<T, 1>(L, Tm, W, N, m, st->gdone[lvl], full, early, s);
+    if (wcan > st->wdone[lvl]) st->wdone[lvl] = wcan;
+    if (full > st->gdone[lvl]) st->gdone[lvl] = full;
+  }
+  if (early) st->pairs_used = nctr_pairs - el.pairs_left;
+  return (int)hipGetLastError();
 }
 
 template <typename T>
 int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long N, T* Tm, T* W, hipStream_t s) {
-  const int nbk = (int)(N / NB);
-  for (int m = 1; m < nbk; m *= 2) {
-    if (m <= 16) trtri_level<T, 64>(L, Tm, W, N, m, s);  // <= 512 tiles of 128^2 would leave the GPU waiting on the longest one
-    else trtri_level<T, 128>(L, Tm, W, N, m, s);
-  }
-  return (int)hipGetLastError();
+  TrtriProgress st;
+  return trtri_advance<T>(L, N, Tm, W, (int)(N / NB), &st, s, 0, nullptr, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -491,7 +661,9 @@ int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s) {
 #define DGP_INST(T)                                                                                              \
   template int posterior_cov<T>(const T*, long, long, T*, hipStream_t);                                          \
   template int symv_lower<T>(const T*, long, const T*, int, const T*, T*, T*, T*, hipStream_t);                  \
-  template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*);                     \
+  template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \
+                        const int*, hipEvent_t*, void (*)(void*, int), void*);                                                                                        \
+  template int trtri_advance<T>(const T*, long, T*, T*, int, TrtriProgress*, hipStream_t, int, int*, int, int);                   \
   template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t);                                          \
   template int lauum<T>(const T*, long, T*, hipStream_t);                                                        \
   template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t);                             \

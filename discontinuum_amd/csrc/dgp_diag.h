@@ -6,7 +6,10 @@
 //   for each 16-column step kb:
 //     GJ16    one wave factors the 16x16 pivot block by an in-register Gauss-Jordan sweep: 16 pivots,
 //             values broadcast with lane shuffles (ds_bpermute / v_readlane), no barrier, no LDS
-//             round trip -> ~200 cycles per pivot instead of ~1400 for a workgroup-wide sweep.
+//             round trip -> ~350 cycles per pivot (measured) instead of ~1400 for a workgroup-wide sweep.
+//             (A sweep that applies each pivot as a rank-1 MFMA on accumulator-layout cells needs no shuffles
+//             but measured SLOWER, ~400-470 cycles per pivot: one wave's dependent fp64 chain, ~10 cycles per
+//             instruction, bounds both.)
 //     panel   L_ik = A_ik L_kk^-T              (MFMA 16x16x4, one sub-block per wave)
 //     update  A_ij -= L_ik L_jk^T, i >= j > kb (MFMA)
 //   then L^-1 by block forward substitution, one block column per wave (columns w and 7-w balance
@@ -137,6 +140,15 @@ __device__ __forceinline__ float frag_rc_acc<float>(const float* blk, int r, int
   return blk[(lane & 15) * DGP_DS + 4 * (lane >> 4) + r];
 }
 
+// optional phase timestamps (scripts/diag_bench.hip builds with -DDGP_DIAG_PROFILE)
+#ifdef DGP_DIAG_PROFILE
+__device__ long long dgp_diag_prof[16];
+#define DGP_DIAG_STAMP(i) \
+  if (threadIdx.x == 0) dgp_diag_prof[i] = clock64();
+#else
+#define DGP_DIAG_STAMP(i)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A, long ld, long k0,
                                                               T* __restrict__ Tinv, T* __restrict__ logdet,
@@ -156,6 +168,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
   T* Xblk = Tinv + k0 * ld + k0;
   // this workgroup usually shares its CU with waves of the bulk trailing update: win the issue arbitration
   __builtin_amdgcn_s_setprio(3);
+  DGP_DIAG_STAMP(0)
 
   // ---- load the lower block triangle (diagonal sub-blocks complete: they are symmetric)
   // (fully unrolled: all 36 global loads are in flight before the first LDS store)
@@ -185,8 +198,10 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
 #pragma unroll
     for (int r = 0; r < 4; ++r) C[Mfma<T>::crow(lane, r) * DGP_DS + (lane & 15)] = acc[r];
   };
+  DGP_DIAG_STAMP(1)
   if (wave == 0) gj16<T>(sL + dtri(0, 0) * DGP_DBLK, sXd, dvals, lane);
   __syncthreads();
+  DGP_DIAG_STAMP(2)
   for (int kb = 0; kb < DGP_DNB - 1; ++kb) {
     // panel: L_ik = A_ik * Linv_kk^T
     const T* Xkk = sXd + kb * DGP_DBLK;
@@ -214,6 +229,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
     __syncthreads();
   }
 
+  DGP_DIAG_STAMP(3)
   // ---- L is final: stream it to global (zeros above the block diagonal); nothing waits for these stores
 #pragma unroll
   for (int bi = 0; bi < DGP_DNB; ++bi)
@@ -221,6 +237,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
     for (int bj = 0; bj < DGP_DNB; ++bj)
       Ablk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = bj <= bi ? sL[dtri(bi, bj) * DGP_DBLK + ti * DGP_DS + tj] : T(0);
 
+  DGP_DIAG_STAMP(4)
   // ---- L^-1 by block forward substitution: wave w owns block columns w and 7 - w.  The finished blocks
   // X_cj of the column stay in REGISTERS (accumulator layout == B-operand layout, see frag_rc_acc), so
   // this phase touches LDS only for its A operands (L_ic, Linv_ii) and global memory only for stores.
@@ -257,6 +274,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
     }
   }
   (void)crow0;
+  DGP_DIAG_STAMP(5)
 
   // ---- diagonal sub-blocks of L^-1 and the zeros above the block diagonal
 #pragma unroll
@@ -264,6 +282,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
 #pragma unroll
     for (int bj = bi; bj < DGP_DNB; ++bj)
       Xblk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = bj == bi ? sXd[bi * DGP_DBLK + ti * DGP_DS + tj] : T(0);
+  DGP_DIAG_STAMP(6)
   // ---- log-determinant and first bad pivot (fixed-order tree: reproducible)
   __shared__ T red[128];
   __shared__ int bad;
@@ -283,6 +302,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
     logdet[0] += red[0];  // diag kernels of one factorisation run in stream order
     if (bad < 128) atomicCAS(info, 0, (int)(k0 + bad + 1));
   }
+  DGP_DIAG_STAMP(7)
 }
 
 template <typename T>

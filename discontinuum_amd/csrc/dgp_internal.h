@@ -33,7 +33,25 @@ int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream
 // ---- dgp_chol.hip ---------------------------------------------------------------------------
 template <typename T>
 int potrf(T* A, long N, T* Dinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
-          hipEvent_t* syrk_ev /* 2 per bulk launch, or null */, int* n_syrk, double* syrk_flop);
+          hipEvent_t* syrk_ev /* 2 per bulk launch, or null */, int* n_syrk, double* syrk_flop,
+          int nck = 0, const int* ck_blocks = nullptr /* ascending */, hipEvent_t* ck_ev = nullptr,
+          void (*on_ck)(void* ctx, int idx) = nullptr /* called right after checkpoint idx is recorded */,
+          void* ck_ctx = nullptr);
+// progress of the level recursion of trtri when it is issued piecewise (trtri_advance)
+struct TrtriProgress {
+  static constexpr int MAXLVL = 16;
+  int wdone[MAXLVL] = {0}, gdone[MAXLVL] = {0};  // per level: groups whose W-step / both steps are launched
+  int pairs_used = 0;                            // counter pairs consumed by queue-driven launches
+};
+template <typename T>
+int trtri_advance(const T* L, long N, T* Tm, T* W, int ready_blocks, TrtriProgress* st, hipStream_t s, int wg_cap,
+                  int* ctr /* info + EARLY_CTR0, or null */, int nctr_pairs, int reserve_cus);
+// info[0] = potrf status; info[EARLY_CTR0 + 2i ..] = (tile queue, worker count) of the i-th early inverse launch
+#define EARLY_CTR0 4
+#define EARLY_CTR_PAIRS 126
+#define POTRF_INFO_INTS (EARLY_CTR0 + 2 * EARLY_CTR_PAIRS)
+// per-device table of compute units kept free of early-inverse workgroups (null if unavailable)
+const unsigned char* reserved_cu_table(int nreserve, int* n_cu);
 template <typename T>
 int trtri(const T* L, const T* Dinv, long N, T* Tm, T* W, hipStream_t s);
 template <typename T>

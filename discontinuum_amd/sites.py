@@ -51,6 +51,10 @@ def fit_sites(plans, Xs, rs, noises, theta):
     if not isinstance(plans, (list, tuple)):
         plans = [plans]
     on_gpu = plans[0].device.type == "cuda"
+    if len(plans) > 1:  # several plans in flight: no third stream per plan (include/dgp_hip.h, dgp_plan_set_lookahead)
+        for p in plans:
+            if hasattr(p, "set_lookahead"):
+                p.set_lookahead(1)
     streams = [torch.cuda.Stream(device=plans[0].device) for _ in plans] if on_gpu else [None] * len(plans)
     if on_gpu:
         ready = torch.cuda.Event()

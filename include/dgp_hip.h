@@ -63,13 +63,19 @@ int dgp_model_ntheta(int model, int d);
 /* padded order N = round_up(n, 128) used by every N x N buffer */
 int64_t dgp_padded_n(int64_t n);
 
-/* A plan fixes (model, dtype, n, d) and owns host-side resources only (a lookahead stream and
- * events).  Device memory is the caller's: query the size, allocate, hand it over. */
+/* A plan fixes (model, dtype, n, d) and owns host-side resources only (up to two internal HIP streams
+ * and events).  Device memory is the caller's: query the size, allocate, hand it over. */
 int dgp_plan_create(int model, int dtype, int64_t n, int d, dgp_plan** out);
 int dgp_plan_destroy(dgp_plan* plan);
 size_t dgp_plan_workspace_bytes(const dgp_plan* plan);
 int dgp_plan_set_workspace(dgp_plan* plan, void* dev_ptr, size_t bytes);
-int dgp_plan_set_lookahead(dgp_plan* plan, int enabled); /* default 1 */
+/* Concurrency inside one fit step.  0: everything in order on the caller's stream.  1: the bulk trailing
+ * updates of the factorisation run on a second (lowest-priority) stream beside the panel chain.  2 (default):
+ * additionally the inverse's level recursion is issued on a third stream behind checkpoints of the
+ * factorisation, filling the CUs its sequential tail leaves idle -- best for ONE plan per GPU; callers that keep
+ * several plans in flight on one GPU should select 1 (the other plans already fill the idle CUs, and every
+ * extra stream costs throughput there). */
+int dgp_plan_set_lookahead(dgp_plan* plan, int level);
 int dgp_plan_buffer(const dgp_plan* plan, int which, void** dev_ptr, int64_t* ld);
 
 /* Training inputs X (n x d row-major, device) -> internal SoA copy.  Replaces the train_x tensor

@@ -43,6 +43,13 @@ int run(const char* name) {
       e2max = fmax(e2max, fabs(t - (i == j)));
     }
   printf("%-10s BS=%d: %.1f us   |LL^T-A|=%.2e  |XL-I|=%.2e\n", name, BS, best * 1e3, e1max, e2max);
+#ifdef DGP_DIAG_PROFILE
+  long long st[16];
+  CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(dgp_diag_prof), sizeof(st)));
+  const char* ph[] = {"load A -> LDS", "first GJ16", "main loop (7 block steps)", "store L", "inverse phase", "store diag X", "logdet"};
+  for (int i = 0; i < 7; ++i) printf("    %-28s %8lld cycles\n", ph[i], st[i + 1] - st[i]);
+  printf("    total %lld cycles (wave 0 thread 0, shader clock)\n", st[7] - st[0]);
+#endif
   return 0;
 }
 int main() { run<double,128,true>("f64"); run<float,128,true>("f32"); return 0; }

@@ -12,7 +12,7 @@ def site(seed):
     return torch.tensor(X, dtype=dt, device=dev), torch.tensor(r.standard_normal(n), dtype=dt, device=dev)
 noise = torch.full((n,), 0.01, dtype=dt, device=dev); theta = [0.6931] * 11
 sites = [site(i) for i in range(16)]
-for conc in (1, 2, 3, 4):
+for conc in (1, 2, 3, 4, 6, 8):
     plans = [GPPlan("loadest", n, d, dtype=dt, device=dev) for _ in range(conc)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(conc)]
     def sweep():

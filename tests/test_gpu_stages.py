@@ -234,6 +234,38 @@ def test_lookahead_schedule_matches_plain_schedule(n, gpu_device):
     assert (o1[4:4 + P] - g_theta).abs().max() / g_theta.abs().max() < 1e-8
 
 
+@pytest.mark.parametrize("n", [2048, 2200, 2500, 3000, 3300])
+def test_early_inverse_matches_in_order_schedule(n, gpu_device):
+    """From 16 block columns on, level 2 issues the inverse's level recursion piecewise behind checkpoints of the
+    factorisation (third stream).  Same kernels, same operands: the inverse factor and K^^-1 must agree with the
+    in-order schedules bit for bit in T (identical launches) and the step results to rounding."""
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    X, r, noise, theta = make_case("loadest", 3, n, seed=n, perturb=0.1)
+    res = {}
+    for level in (2, 1, 0):
+        p = plan_for("loadest", 3, n, X, torch.float64, dev, lookahead=level)
+        out, dr, dn = p.fit_step(theta, r.to(dev), noise.to(dev))
+        torch.cuda.synchronize()
+        res[level] = (out.cpu(), dr.cpu(), tril_n(p.buffer(_lib.BUF_T), n), tril_n(p.buffer(_lib.BUF_S), n))
+    o2, a2, T2, S2 = res[2]
+    assert o2[_lib.OUT_INFO] == 0
+    P = theta.numel()
+    for level in (1, 0):
+        o, a, Tm, S = res[level]
+        assert abs(o2[0] - o[0]) / abs(o[0]) < 1e-12
+        assert (o2[4:4 + P] - o[4:4 + P]).abs().max() / o[4:4 + P].abs().max() < 1e-9
+        assert (a2 - a).abs().max() / a.abs().max() < 1e-9
+        assert (T2 - Tm).abs().max() <= 1e-9 * Tm.abs().max()
+        assert (S2 - S).abs().max() <= 1e-9 * S.abs().max()
+    assert torch.equal(T2, res[1][2])  # levels 2 and 1 share the factorisation schedule: identical inverse
+    # and the factor really is the inverse: T K^ T^T = I on a probe
+    Khat = orc.GRAMS["loadest"](X, X, theta) + torch.diag(noise)
+    probe = torch.randn(n, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    assert (S2 @ (Khat @ probe) + torch.tril(S2, -1).T @ (Khat @ probe) - probe).abs().max() < 1e-6
+
+
 @pytest.mark.parametrize("model,d,n", [("loadest", 2, 1), ("loadest", 2, 2), ("loadest", 3, 17), ("loadest", 2, 127),
                                        ("loadest", 3, 128), ("loadest", 2, 129), ("rating", 2, 3), ("rating", 2, 257)])
 def test_edge_sizes_fp64(model, d, n, gpu_device):
