@@ -209,8 +209,14 @@ static int ensure_async(dgp_plan* p) {
 
 // the third stream exists only for plans that use it: every extra stream per plan costs throughput once
 // several plans share the GPU (measured 86 -> 78 fits/s with two plans), so batched callers select level 1
+static bool early_applies(const dgp_plan* p) {
+  // measured (fp64, one site): n = 2048 -1 %, 4096 -3 %, 8192 -6 %, 12288 +0.3 %, 16384 +0.8 %, 32768 (fp32) +6 %:
+  // beyond ~10k the factorisation is bound by its bulk updates, not by the panel chain, and has no idle tail
+  const int nbk = (int)(p->N / DGP_TILE_HOST);
+  return p->early && p->lookahead >= 2 && nbk >= 16 && nbk <= 80;
+}
 static int ensure_early(dgp_plan* p) {
-  if (!p->early || !p->lookahead || p->s3) return 0;
+  if (!early_applies(p) || p->s3) return 0;  // an idle extra stream is not free either (n = 32768: 293 -> 305 ms)
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   hipError_t e = hipStreamCreateWithPriority(&p->s3, hipStreamNonBlocking, least);
@@ -305,7 +311,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
   if ((rc = ensure_async(p)) || (rc = ensure_early(p))) return rc;
   tick(p, TS_POTRF, 0, s);
   const int nbk = (int)(p->N / DGP_TILE_HOST);
-  const bool early = p->early && p->lookahead >= 2 && p->s3 != nullptr && nbk >= 16;
+  const bool early = early_applies(p) && p->s3 != nullptr;
   if (early) {
     // The factorisation's tail is a sequential panel chain that leaves most CUs idle, and the inverse's level
     // recursion only needs the block columns that are already final: issue it piecewise on s3 behind
