@@ -52,30 +52,80 @@ __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T
 // (bulk trailing update; nk = 2 halves the passes over the trailing matrix: 53.6 vs 44.5 TFLOP/s in isolation).
 // The accumulators start at -C, so the read of C overlaps the first operand loads and the epilogue
 // is store-only:  C_new = -( -C + P_i P_j^T ).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg) {
-  using G = TileGemm<T, true, true>;
-  __shared__ T smem[G::SMEM_ELEMS];
-  int bi, bj;
-  tri_decode(xcd_remap((int)blockIdx.x, (int)gridDim.x), bi, bj);  // all tiles cost the same: remap freely
-  bi += jbeg;
-  bj += jbeg;
+//
+// All tiles cost the same and the GPU holds 512 of these workgroups at a time, so a launch of t tiles runs in
+// ceil(t / 512) rounds and its last round is on average half empty.  The first `nfull` tiles (whole rounds) are
+// done as 128 x 128 tiles; the rest is cut into `split` pieces each (2: 64 x 128 halves, 4: 64 x 64 quarters),
+// which fills the last round at a fraction of its time (SyrkShape picks the cheapest cut).
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int nk, long row0, long col0,
+                                          T* __restrict__ smem) {
+  using G = TileGemm<T, true, true, BM, BN>;
   typename G::acc_t acc[G::MI][G::NI];
-  T* C = A + (long)bi * NB * ld + (long)bj * NB;
+  T* C = A + row0 * ld + col0;
   G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * ld + c]; });
-  G::template run<Prefetch<T>::SYRK>(A + (long)bi * NB * ld + (long)k * NB, ld, A + (long)bj * NB * ld + (long)k * NB, ld,
-                                     nk * (NB / 16), smem, acc);
+  G::template run<(BM == 128 && BN == 128) ? Prefetch<T>::SYRK : 1>(A + row0 * ld + (long)k * NB, ld,
+                                                                   A + col0 * ld + (long)k * NB, ld, nk * (NB / 16),
+                                                                   smem, acc);
   G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] = -v; });
 }
 
-// the lookahead column: only block column jcol, 64x64 tiles (latency-critical, see trsm_kernel)
 template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int nk, int jcol) {
+__global__ __launch_bounds__(256, 2) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg, int nfull,
+                                                      int split) {
+  __shared__ T smem[TileGemm<T, true, true>::SMEM_ELEMS];
+  const int b = (int)blockIdx.x;
+  int bi, bj;
+  if (b < nfull) {
+    tri_decode(xcd_remap(b, nfull), bi, bj);  // all tiles cost the same: remap freely
+    syrk_tile<T, 128, 128>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem);
+    return;
+  }
+  const int sub = b - nfull;
+  tri_decode(nfull + sub / split, bi, bj);
+  const long row0 = (long)(bi + jbeg) * NB, col0 = (long)(bj + jbeg) * NB;
+  const int part = sub % split;
+  if (split == 2) {
+    syrk_tile<T, 64, 128>(A, ld, k, nk, row0 + 64 * part, col0, smem);
+  } else {
+    if (bi == bj && part == 1) return;  // strictly upper quadrant of a diagonal tile
+    syrk_tile<T, 64, 64>(A, ld, k, nk, row0 + 64 * (part >> 1), col0 + 64 * (part & 1), smem);
+  }
+}
+
+// grid shape of one bulk launch: whole rounds of full tiles + the remainder cut into `split` pieces
+struct SyrkShape {
+  int nfull, split;
+  unsigned grid;
+  explicit SyrkShape(int ntiles, int slots = 512) {
+    // relative cost of one round of 128x128 / 64x128 / 64x64 tiles (the small ones reach ~87 % of the big tile's rate)
+    const double cost[5] = {0, 1.0, 0.55, 0, 0.30};
+    const int whole = ntiles / slots * slots, rem = ntiles - whole;
+    nfull = ntiles;
+    split = 1;
+    double best = (ntiles + slots - 1) / slots * cost[1];
+    for (int g = 2; g <= 4; g += 2) {
+      const double c = whole / slots * cost[1] + (g * rem + slots - 1) / slots * cost[g];
+      if (rem > 0 && c < best - 1e-9) {
+        best = c;
+        nfull = whole;
+        split = g;
+      }
+    }
+    grid = (unsigned)(nfull + split * (ntiles - nfull));
+  }
+};
+
+// the lookahead columns: block columns jcol + blockIdx.z only, 64x64 tiles (latency-critical, see trsm_kernel)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int nk, int jcol, int nbk) {
   using G = TileGemm<T, true, true, 64, 64>;
   __shared__ T smem[G::SMEM_ELEMS];
   __builtin_amdgcn_s_setprio(3);  // panel chain: outrank co-resident bulk-update waves
-  const long row0 = (long)jcol * NB + (long)blockIdx.x * 64;
-  const long col0 = (long)jcol * NB + (long)blockIdx.y * 64;
+  const int jc = jcol + (int)blockIdx.z;
+  if ((int)blockIdx.x >= 2 * (nbk - jc)) return;  // the second column is one block shorter
+  const long row0 = (long)jc * NB + (long)blockIdx.x * 64;
+  const long col0 = (long)jc * NB + (long)blockIdx.y * 64;
   if (col0 > row0 + 63) return;  // strictly upper 64x64 quadrant of the diagonal block
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
@@ -132,7 +182,10 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
       if (k + 1 < nbk) {
         trsm_kernel<T><<<2 * (nbk - k - 1), 256, 0, s>>>(A, Tinv, N, k);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
-        syrk_kernel<T><<<tri(nbk - k - 1), 256, 0, s>>>(A, N, k, 1, k + 1);
+        {
+          const SyrkShape sh((int)tri(nbk - k - 1));
+          syrk_kernel<T><<<sh.grid, 256, 0, s>>>(A, N, k, 1, k + 1, sh.nfull, sh.split);
+        }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s);
         flop += tile_flop * tri(nbk - k - 1);
         ++ns;
@@ -145,35 +198,40 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
   }
   if (lookahead >= 2) {
     // PAIR-AHEAD schedule.  Pair q = panels (2q, 2q+1).  The chain on stream s factors pair q+1 while the bulk
-    // update of pair q runs on s2, so consecutive bulk launches follow each other without a gap:
-    //   chain(q):  [wait U[q-2]]  col 2q   <- pair q-1 (K=256)            diag(2q)    trsm(2q)
-    //                             col 2q+1 <- pair q-1 + panel 2q (K=384) diag(2q+1)  trsm(2q+1)   record P[q]
-    //   bulk(q):   [wait P[q]]    block columns >= 2q+4 <- pair q (K=256)                           record U[q]
+    // update of pair q runs on s2, so consecutive bulk launches follow each other without waiting for a panel:
+    //   chain(q):  [wait U[q-2]]  cols 2q, 2q+1 <- pair q-1 (K=256, one launch)    record P[q-1]
+    //                             diag(2q)  trsm(2q)  col 2q+1 <- panel 2q (K=128)  diag(2q+1)  trsm(2q+1)
+    //   bulk(q-1): [wait P[q-1]]  block columns >= 2q+2 <- pair q-1 (K=256)                     record U[q-1]
     // Column c gets pairs <= c/2-2 from the bulk launches, pair c/2-1 and its own pair's first panel from the chain.
+    // bulk(q-1) is released only once the chain's two-column update for pair q is through: released together, the
+    // bulk launch takes every CU slot first and that update (the widest chain kernel) runs ~100 us instead of ~20;
+    // the chain, not the bulk stream, is what the first half of the factorisation waits for.
     hipEvent_t* P = ev;
     hipEvent_t* U = ev + nbk;
     const int Q = (nbk + 1) / 2;
     for (int q = 0; q < Q; ++q) {
+      const int k0 = 2 * q, ncol = k0 + 1 < nbk ? 2 : 1;
       if (q >= 2) hipStreamWaitEvent(s, U[q - 2], 0);  // bulk(q-2) exists whenever chain(q) does
-      for (int h = 0; h < 2; ++h) {
-        const int k = 2 * q + h;
-        if (k >= nbk) break;
-        const int kfirst = q >= 1 ? 2 * q - 2 : 2 * q;
-        const int nk = k - kfirst;  // panels not yet applied to column k
-        if (nk > 0) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2), 256, 0, s>>>(A, N, kfirst, nk, k);
+      if (q >= 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k0), 2, ncol), 256, 0, s>>>(A, N, k0 - 2, 2, k0, nbk);
+      if (q >= 1 && k0 + 2 < nbk) {  // bulk(q-1): columns >= 2q+2 exist
+        hipEventRecord(P[q - 1], s);
+        hipStreamWaitEvent(s2, P[q - 1], 0);
+        if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
+        {
+          const SyrkShape sh((int)tri(nbk - k0 - 2));
+          syrk_kernel<T><<<sh.grid, 256, 0, s2>>>(A, N, k0 - 2, 2, k0 + 2, sh.nfull, sh.split);
+        }
+        if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
+        flop += 2.0 * tile_flop * tri(nbk - k0 - 2);
+        ++ns;
+        hipEventRecord(U[q - 1], s2);
+      }
+      for (int h = 0; h < ncol; ++h) {
+        const int k = k0 + h;
+        if (h == 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2, 1), 256, 0, s>>>(A, N, k0, 1, k, nbk);
         launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s);
         if (k + 1 < nbk) trsm_kernel<T><<<2 * (nbk - k - 1), 256, 0, s>>>(A, Tinv, N, k);
         checkpoint(k + 1);
-      }
-      if (2 * q + 4 < nbk) {
-        hipEventRecord(P[q], s);
-        hipStreamWaitEvent(s2, P[q], 0);
-        if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
-        syrk_kernel<T><<<tri(nbk - 2 * q - 4), 256, 0, s2>>>(A, N, 2 * q, 2, 2 * q + 4);
-        if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
-        flop += 2.0 * tile_flop * tri(nbk - 2 * q - 4);
-        ++ns;
-        hipEventRecord(U[q], s2);
       }
     }
     // bulk(q) exists for q <= Q-3 and chain(q+2) has waited on every one of them: s is joined
@@ -199,7 +257,10 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     if (odd && k + 2 < nbk) {
       hipStreamWaitEvent(s2, P[k], 0);
       if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
-      syrk_kernel<T><<<tri(nbk - k - 2), 256, 0, s2>>>(A, N, k - 1, 2, k + 2);
+      {
+        const SyrkShape sh((int)tri(nbk - k - 2));
+        syrk_kernel<T><<<sh.grid, 256, 0, s2>>>(A, N, k - 1, 2, k + 2, sh.nfull, sh.split);
+      }
       if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
       flop += 2.0 * tile_flop * tri(nbk - k - 2);
       ++ns;
@@ -211,8 +272,8 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
       hipStreamWaitEvent(s, U[p - 1], 0);
       last_u = p - 1;
     }
-    if (odd) syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k - 1, 2, k + 1);
-    else syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k, 1, k + 1);
+    if (odd) syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k - 1, 2, k + 1, nbk);
+    else syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k, 1, k + 1, nbk);
     launch_diag<T>(A, N, (long)(k + 1) * NB, Tinv, logdet, info, s);
     if (k + 2 < nbk) {
       trsm_kernel<T><<<2 * (nbk - k - 2), 256, 0, s>>>(A, Tinv, N, k + 1);
