@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lookahead", action="store_true")
     ap.add_argument("--sites-per-gpu", type=int, default=2)
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the per-kernel timing loop of the roofline object (the command profiled with "
+                         "rocprofv3 --kernel-trace --stats for profiles/)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,6 +128,8 @@ def main():
 
     dt = torch.float64 if args.dtype == "f64" else torch.float32
     n, d, S = args.n, args.d, max(1, args.sites_per_gpu)
+    if args.roofline_only:
+        S = 1
     ntheta = 2 * d + 5
     theta = [0.6931471805599453] * ntheta  # gpytorch defaults: softplus(0)
     noise = torch.full((n,), 0.01, dtype=dt, device=dev)
@@ -152,6 +157,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.roofline_only:
+        plan.set_lookahead(0 if args.no_lookahead else 1)  # the default run's roofline schedule
+        plan.set_timing(True)
+        for _ in range(max(3, args.steps)):
+            plan.fit_step(theta, ys[0], noise)
+        torch.cuda.synchronize()
+        ms = plan.get_timing()
+        print(json.dumps({"roofline_only": True, "kernel": "syrk_kernel", "launches": int(ms[_lib.TIME_SYRK_N]),
+                          "ms_per_step": ms[_lib.TIME_SYRK_SUM],
+                          "avg_launch_us": 1e3 * ms[_lib.TIME_SYRK_SUM] / max(1, int(ms[_lib.TIME_SYRK_N])),
+                          "achieved_tflops": ms[_lib.TIME_SYRK_FLOP] / (ms[_lib.TIME_SYRK_SUM] * 1e-3) / 1e12}))
+        return
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         outs = batch_step()

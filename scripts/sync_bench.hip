@@ -14,7 +14,10 @@ int main() {
   for (int i = 0; i < 256; ++i) { CK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)); CK(hipEventCreate(&evt[i])); }
   CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
   const int N = 100; const long cyc = 20000;  // ~10 us kernels (clock64 ticks at 100 MHz? measured below)
-  for (int mode = 0; mode < 7; ++mode) {
+  uint32_t *sigA = nullptr, *sigB = nullptr;  // signal memory for hipStreamWriteValue32 / hipStreamWaitValue32
+  CK(hipExtMallocWithFlags((void**)&sigA, 8, hipMallocSignalMemory)); CK(hipExtMallocWithFlags((void**)&sigB, 8, hipMallocSignalMemory));
+  uint32_t epoch = 0;
+  for (int mode = 0; mode < 8; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipDeviceSynchronize());
       CK(hipEventRecord(t0, s));
@@ -29,6 +32,12 @@ int main() {
           CK(hipEventRecord(ev[i], s)); CK(hipStreamWaitEvent(s2, ev[i], 0));
           spin<<<1, 64, 0, s2>>>(cyc, nullptr);
           CK(hipEventRecord(ev[128 + i], s2)); CK(hipStreamWaitEvent(s, ev[128 + i], 0));
+        }
+        if (mode == 7) {  // ping-pong through memory values instead of events
+          ++epoch;
+          CK(hipStreamWriteValue32(s, sigA, epoch, 0)); CK(hipStreamWaitValue32(s2, sigA, epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
+          spin<<<1, 64, 0, s2>>>(cyc, nullptr);
+          CK(hipStreamWriteValue32(s2, sigB, epoch, 0)); CK(hipStreamWaitValue32(s, sigB, epoch, hipStreamWaitValueGte, 0xFFFFFFFFu));
         }
         if (mode == 6) {  // fork only: s2 waits on s each iteration, s never waits
           CK(hipEventRecord(ev[i], s)); CK(hipStreamWaitEvent(s2, ev[i], 0));
