@@ -5,17 +5,18 @@
 
 One "fit" = one `dgp_fit_step` through the C ABI: Gram build, blocked Cholesky, L^-1, K^^-1, NLL and all
 hyperparameter / residual / noise gradients for one site, inputs resident in HBM (BASELINE.json
-configs[1]).  One "step" = one batch of `--sites-per-gpu` (default 2) INDEPENDENT
-sites per GPU, each on its own plan and HIP stream -- the north star's "independent sites /
-hyperparameter-sample batches": while one site sits in the sequential panel chain of its factorisation
-the other's GEMM-heavy stages use the idle CUs.  `value` = fits/s over all sites and GPUs; the latency of a
-single site alone on the GPU is reported next to it (`single_site`), and the roofline numbers come from
-that single-site loop (no co-running kernels).  With N > 1 every rank owns its own sites (seeds
-rank*S .. rank*S+S-1, weak scaling, no data-path collective); the only RCCL traffic is the gather of the
+configs[1]).  One "step" = one fit of each of `--sites-per-gpu` (default 8) INDEPENDENT
+sites per GPU, carried in lockstep by ONE batched plan (`dgp_plan_set_batch`): every kernel of the step is
+launched once for all of them (gridDim.z = sites) -- the north star's "independent sites / hyperparameter-sample
+batches".  A single fit is bound by the sequential panel chain of its factorisation for half of its time; over
+a batch that chain and the launch rate are amortised and the step becomes GEMM-bound.  `value` = fits/s over all
+sites and GPUs; the latency of one site alone on the GPU (a single fit loop, `--sites-per-gpu 1` is the same
+thing as the timed region) is reported next to it (`single_site`).  With N > 1 every rank owns its own sites
+(seeds rank*S .. rank*S+S-1, weak scaling, no data-path collective); the only RCCL traffic is the gather of the
 (NLL, gradient) rows at the end of the timed region.  Rank 0 prints ONE JSON line.
 
 `roofline`     dominant kernel of the step, timed live with HIP events recorded inside the library on the
-               stream each kernel is launched on (last timed step).  Algorithmic flops per DESIGN.md.
+               stream each kernel is launched on (last step of the timed region).  Algorithmic flops per DESIGN.md.
 `cpu_baseline` the CPU oracle (a dense torch fp64 restatement of the reference's gpytorch math -- gpytorch
                itself is not installable here) timed on the host cores, rank 0 / N=1 only, bounded sample.
 """
@@ -93,7 +94,8 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lookahead", action="store_true")
-    ap.add_argument("--sites-per-gpu", type=int, default=2)
+    ap.add_argument("--sites-per-gpu", type=int, default=8,
+                    help="independent sites carried in lockstep by one batched plan per GPU (1..8)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the per-kernel timing loop of the roofline object (the command profiled with "
                          "rocprofv3 --kernel-trace --stats for profiles/)")
@@ -128,42 +130,44 @@ def main():
 
     dt = torch.float64 if args.dtype == "f64" else torch.float32
     n, d, S = args.n, args.d, max(1, args.sites_per_gpu)
-    if args.roofline_only:
-        S = 1
     ntheta = 2 * d + 5
     theta = [0.6931471805599453] * ntheta  # gpytorch defaults: softplus(0)
     noise = torch.full((n,), 0.01, dtype=dt, device=dev)
-    plans, streams, ys = [], [], []
-    for sidx in range(S):  # S independent sites per rank, each with its own plan and stream
+    # S independent sites per rank carried by ONE batched plan: every kernel of the fit step is launched once for
+    # all S sites (gridDim.z = S), so the sequential panel chain and the launch rate are amortised over them.
+    # The single-site plan (latency, roofline) uses the default level 2 (early inverse on a third stream).
+    Xs, ys = [], []
+    for sidx in range(S):
         X, y = synth_loadest(n, d, seed=rank * S + sidx)
-        # several plans in flight on one GPU: level 1 (their stages fill each other's idle CUs); the single-site
-        # plan below uses the default level 2 (early inverse on a third stream)
-        p = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=0 if args.no_lookahead else (1 if S > 1 else 2))
-        p.set_inputs(torch.tensor(X, dtype=dt, device=dev).contiguous())
-        plans.append(p)
+        Xs.append(torch.tensor(X, dtype=dt, device=dev))
         ys.append(torch.tensor(y, dtype=dt, device=dev).contiguous())
-        streams.append(torch.cuda.Stream(device=dev))
-    plan = plans[0]
+    level = 0 if args.no_lookahead else (1 if S > 1 else 2)
+    plan = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=0 if args.no_lookahead else 2)
+    plan.set_inputs(Xs[0].contiguous())
+    if S > 1:
+        bplan = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=level, batch=S)
+        bplan.set_inputs(torch.stack(Xs).contiguous())
+        ball = torch.stack(ys).contiguous()
+        bnoise = noise.repeat(S, 1).contiguous()
+        btheta = theta * S
+    else:
+        bplan, ball, bnoise, btheta = plan, ys[0], noise, theta
 
     def batch_step():
-        outs = []
-        for p, st, y in zip(plans, streams, ys):
-            with torch.cuda.stream(st):
-                outs.append(p.fit_step(theta, y, noise)[0])
-        return outs
+        out = bplan.fit_step(btheta, ball, bnoise)[0]
+        return list(out) if S > 1 else [out]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    bplan.set_timing(True)  # HIP events around every bulk launch, on the stream it runs on (the roofline object)
     if args.roofline_only:
-        plan.set_lookahead(0 if args.no_lookahead else 1)  # the default run's roofline schedule
-        plan.set_timing(True)
         for _ in range(max(3, args.steps)):
-            plan.fit_step(theta, ys[0], noise)
+            batch_step()
         torch.cuda.synchronize()
-        ms = plan.get_timing()
+        ms = bplan.get_timing()
         print(json.dumps({"roofline_only": True, "kernel": "syrk_kernel", "launches": int(ms[_lib.TIME_SYRK_N]),
                           "ms_per_step": ms[_lib.TIME_SYRK_SUM],
                           "avg_launch_us": 1e3 * ms[_lib.TIME_SYRK_SUM] / max(1, int(ms[_lib.TIME_SYRK_N])),
@@ -193,9 +197,6 @@ def main():
     # ---- single-site loop on rank 0: latency of one fit alone on the GPU + per-kernel HIP-event timings
     single_ms = None
     if rank == 0:
-        level = 0 if args.no_lookahead else (1 if S > 1 else 2)  # what the timed region above ran with
-        if not args.no_lookahead:
-            plan.set_lookahead(2)  # alone on the GPU: also issue the inverse early (third stream)
         ksingle = max(3, args.steps // 2)
         plan.fit_step(theta, ys[0], noise)
         torch.cuda.synchronize()
@@ -204,24 +205,17 @@ def main():
             plan.fit_step(theta, ys[0], noise)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / ksingle * 1e3
-        # per-kernel HIP-event timings for the roofline: same schedule as the timed region, one site at a time
-        # (the events bracket every bulk launch on the stream it runs on; the last step is reported)
-        plan.set_lookahead(level)
-        plan.set_timing(True)
-        for _ in range(3):
-            plan.fit_step(theta, ys[0], noise)
-        torch.cuda.synchronize()
 
     if rank == 0:
         N = plan.N
-        ms = plan.get_timing()
+        ms = bplan.get_timing()  # last step of the timed region
         esz = 8 if args.dtype == "f64" else 4
         peak = PEAK_TFLOPS[args.dtype]
         f_syrk = ms[_lib.TIME_SYRK_FLOP]  # algorithmic flops of the bulk launches, reported by the library
         stages = {
             "syrk_kernel": {"flops": f_syrk, "ms": ms[_lib.TIME_SYRK_SUM], "launches": int(ms[_lib.TIME_SYRK_N])},
-            "trtri_level_kernel": {"flops": N ** 3 / 3.0, "ms": ms[_lib.TIME_TRTRI], "launches": None},
-            "lauum_kernel": {"flops": N ** 3 / 3.0, "ms": ms[_lib.TIME_LAUUM], "launches": 1},
+            "trtri_level_kernel": {"flops": S * N ** 3 / 3.0, "ms": ms[_lib.TIME_TRTRI], "launches": None},
+            "lauum_kernel": {"flops": S * N ** 3 / 3.0, "ms": ms[_lib.TIME_LAUUM], "launches": 1},
         }
         if level == 2:  # most of the inverse ran under the factorisation: its stage time is only the remainder
             stages["trtri_level_kernel"]["flops"] = None
@@ -251,7 +245,7 @@ def main():
                           "trtri": ms[_lib.TIME_TRTRI], "lauum": ms[_lib.TIME_LAUUM], "solve": ms[_lib.TIME_SOLVE],
                           "grad": ms[_lib.TIME_GRAD]},
             "fit_flops": float(N) ** 3, "job_tflops": float(N) ** 3 * world * S * args.steps / elapsed / 1e12,
-            "measured_in": "one site at a time on the GPU with the timed region's schedule (lookahead level %d), last of 3 steps" % level,
+            "measured_in": "the timed region itself (last step): every launch carries %d site(s), lookahead level %d" % (S, level),
             "gram_hbm": {"bound": "hbm", "achieved": gram_bytes / (ms[_lib.TIME_GRAM] * 1e-3) / 1e9 if ms[_lib.TIME_GRAM] > 0 else None,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes": gram_bytes},
         }
@@ -269,7 +263,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"synthetic loadest-gp kernel, n={n} d={d} {args.dtype} exact GP, "
-                                   f"{S} independent site(s) in flight per GPU (one step = one fit of each)",
+                                   f"{S} independent site(s) per GPU in one batched plan (one step = one fit of each)",
                        "n": n, "d": d, "sites_per_gpu": S, "fits_per_step": world * S,
                        "lookahead": not args.no_lookahead, "nll_site0": float(host[0, _lib.OUT_NLL])},
             "single_site": {"fits_per_s": 1e3 / single_ms, "ms_per_fit": single_ms,

@@ -43,6 +43,8 @@ SIGNATURES = {
     "dgp_plan_workspace_bytes": (_sz, [_vp]),
     "dgp_plan_set_workspace": (_i, [_vp, _vp, _sz]),
     "dgp_plan_set_lookahead": (_i, [_vp, _i]),
+    "dgp_plan_set_batch": (_i, [_vp, _i]),
+    "dgp_plan_batch": (_i, [_vp]),
     "dgp_plan_buffer": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64)]),
     "dgp_set_inputs": (_i, [_vp, _vp, _vp]),
     "dgp_fit_step": (_i, [_vp, _dp, _vp, _vp, _vp, _vp, _vp, _vp]),

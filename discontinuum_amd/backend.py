@@ -37,9 +37,12 @@ def _ptr(t):
 class GPPlan:
     """Fixed (model, dtype, n, d) exact-GP problem resident on one GPU."""
 
-    def __init__(self, model: str, n: int, d: int, dtype=torch.float64, device="cuda", lookahead=True):
+    def __init__(self, model: str, n: int, d: int, dtype=torch.float64, device="cuda", lookahead=True, batch: int = 1):
         """``lookahead``: False / 0 = one stream; 1 = bulk updates beside the panel chain (use this when several
-        plans share one GPU); True / 2 = also the early inverse on a third stream (best for one plan per GPU)."""
+        plans share one GPU); True / 2 = also the early inverse on a third stream (best for one plan per GPU).
+        ``batch`` > 1: the plan carries that many independent sites in lockstep (one launch per kernel for all of
+        them); ``set_inputs`` / ``fit_step`` / ``factorize`` then take batch-major arrays -- X (batch, n, d),
+        theta (batch, ntheta), r / noise (batch, n) -- and return (batch, 32), (batch, n), (batch, n)."""
         if model not in MODELS:
             raise ValueError(f"unknown model {model!r}; expected one of {sorted(MODELS)}")
         if dtype not in _DTYPES:
@@ -56,6 +59,9 @@ class GPPlan:
         handle = C.c_void_p()
         _lib.check(self.lib.dgp_plan_create(MODELS[model], _DTYPES[dtype], self.n, self.d, C.byref(handle)), "dgp_plan_create")
         self._h = handle
+        self.batch = int(batch)
+        if self.batch != 1:
+            _lib.check(self.lib.dgp_plan_set_batch(self._h, self.batch), "dgp_plan_set_batch")
         nbytes = int(self.lib.dgp_plan_workspace_bytes(self._h))
         with torch.cuda.device(self.device):
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
@@ -84,7 +90,7 @@ class GPPlan:
         _lib.check(self.lib.dgp_plan_set_lookahead(self._h, level), "dgp_plan_set_lookahead")
 
     def _check_vec(self, t, name, length=None):
-        length = self.n if length is None else length
+        length = (self.n if length is None else length) * self.batch
         if not (torch.is_tensor(t) and t.is_cuda and t.dtype == self.dtype and t.is_contiguous() and t.numel() == length):
             raise ValueError(f"{name} must be a contiguous {self.dtype} CUDA tensor with {length} elements")
 
@@ -112,11 +118,12 @@ class GPPlan:
         """-> (out[32], alpha[n], dnoise[n]) device tensors; see include/dgp_hip.h DGP_OUT_*."""
         self._check_vec(r, "r")
         self._check_vec(noise, "noise")
-        th = _theta_array(theta, self.ntheta)
+        th = _theta_array(theta, self.ntheta * self.batch)
+        shape = (lambda k: (k,)) if self.batch == 1 else (lambda k: (self.batch, k))
         with torch.cuda.device(self.device):
-            out = torch.empty(_lib.OUT_LEN, dtype=self.dtype, device=self.device)
-            dr = torch.empty(self.n, dtype=self.dtype, device=self.device)
-            dnoise = torch.empty(self.n, dtype=self.dtype, device=self.device)
+            out = torch.empty(shape(_lib.OUT_LEN), dtype=self.dtype, device=self.device)
+            dr = torch.empty(shape(self.n), dtype=self.dtype, device=self.device)
+            dnoise = torch.empty(shape(self.n), dtype=self.dtype, device=self.device)
             _lib.check(
                 self.lib.dgp_fit_step(self._h, th, _ptr(r), _ptr(noise), _ptr(out), _ptr(dr), _ptr(dnoise), _stream()),
                 "dgp_fit_step",
@@ -126,9 +133,10 @@ class GPPlan:
     def factorize(self, theta, r: torch.Tensor, noise: torch.Tensor):
         self._check_vec(r, "r")
         self._check_vec(noise, "noise")
-        th = _theta_array(theta, self.ntheta)
+        th = _theta_array(theta, self.ntheta * self.batch)
         with torch.cuda.device(self.device):
-            out = torch.empty(_lib.OUT_LEN, dtype=self.dtype, device=self.device)
+            out = torch.empty(_lib.OUT_LEN if self.batch == 1 else (self.batch, _lib.OUT_LEN), dtype=self.dtype,
+                              device=self.device)
             _lib.check(self.lib.dgp_factorize(self._h, th, _ptr(r), _ptr(noise), _ptr(out), _stream()), "dgp_factorize")
         return out
 
@@ -258,7 +266,7 @@ class GPPlan:
     def stage_gram(self, theta, noise):
         self._check_vec(noise, "noise")
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.dgp_stage_gram(self._h, _theta_array(theta, self.ntheta), _ptr(noise), _stream()), "dgp_stage_gram")
+            _lib.check(self.lib.dgp_stage_gram(self._h, _theta_array(theta, self.ntheta * self.batch), _ptr(noise), _stream()), "dgp_stage_gram")
 
     def stage_potrf(self):
         with torch.cuda.device(self.device):

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "../../include/dgp_hip.h"
+#include "dgp_common.h"
 #include "dgp_internal.h"
 
 using namespace dgp;
@@ -21,6 +22,8 @@ static int hipfail(hipError_t e, const char* where) {
 
 struct dgp_plan {
   int model, dtype, d, ntheta;
+  int B;                  // sites carried in lockstep (1 = plain plan); site b's buffers sit b * site_bytes further on
+  size_t site_bytes;
   int64_t n, N;
   size_t elem;
   char* ws;
@@ -67,12 +70,7 @@ static Layout layout(const dgp_plan* p) {
   return L;
 }
 
-// potrf schedule: 2 = pair-ahead lookahead (default), 1 = one-panel lookahead; DGP_LOOKAHEAD overrides (tuning only)
-static int default_lookahead() {
-  const char* e = getenv("DGP_LOOKAHEAD");
-  const int v = e ? atoi(e) : 2;
-  return v < 1 ? 1 : (v > 2 ? 2 : v);
-}
+static int default_lookahead() { return 2; }  // the pair-ahead schedule of dgp_chol.hip::potrf
 
 // workgroups the EARLY inverse launches may occupy (one per CU): they share the GPU with the panel chain
 static int early_wg_cap() {
@@ -110,6 +108,7 @@ int dgp_plan_create(int model, int dtype, int64_t n, int d, dgp_plan** out) {
   p->n = n;
   p->N = round_up(n, DGP_TILE_HOST);
   p->elem = dtype == DGP_F64 ? 8 : 4;
+  p->B = 1;
   p->lookahead = default_lookahead();
   p->early = getenv("DGP_NO_EARLY_TRTRI") ? 0 : 1;
   *out = p;
@@ -138,12 +137,22 @@ int dgp_plan_destroy(dgp_plan* p) {
   return 0;
 }
 
-size_t dgp_plan_workspace_bytes(const dgp_plan* p) { return p ? layout(p).total : 0; }
+size_t dgp_plan_workspace_bytes(const dgp_plan* p) { return p ? layout(p).total * (size_t)p->B : 0; }
+
+int dgp_plan_set_batch(dgp_plan* p, int batch) {
+  if (!p) return fail(DGP_E_ARG, "null plan");
+  if (batch < 1 || batch > DGP_MAX_BATCH_HOST) return fail(DGP_E_ARG, "dgp_plan_set_batch: batch must be 1..8");
+  if (p->ws) return fail(DGP_E_STATE, "dgp_plan_set_batch: call before dgp_plan_set_workspace");
+  p->B = batch;
+  return 0;
+}
+int dgp_plan_batch(const dgp_plan* p) { return p ? p->B : 0; }
 
 int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   if (!p || !dev_ptr) return fail(DGP_E_ARG, "dgp_plan_set_workspace: null");
   const Layout L = layout(p);
-  if (bytes < L.total) return fail(DGP_E_WORKSPACE, "dgp_plan_set_workspace: workspace too small");
+  if (bytes < L.total * (size_t)p->B) return fail(DGP_E_WORKSPACE, "dgp_plan_set_workspace: workspace too small");
+  p->site_bytes = L.total;
   if (((uintptr_t)dev_ptr & 255) != 0) return fail(DGP_E_ARG, "dgp_plan_set_workspace: pointer must be 256-byte aligned");
   p->ws = (char*)dev_ptr;
   p->ws_bytes = bytes;
@@ -210,6 +219,7 @@ static int ensure_async(dgp_plan* p) {
 // the third stream exists only for plans that use it: every extra stream per plan costs throughput once
 // several plans share the GPU (measured 86 -> 78 fits/s with two plans), so batched callers select level 1
 static bool early_applies(const dgp_plan* p) {
+  if (p->B != 1) return false;  // a batched plan's sites already fill each other's idle CUs
   // measured (fp64, one site): n = 2048 -1 %, 4096 -3 %, 8192 -6 %, 12288 +0.3 %, 16384 +0.8 %, 32768 (fp32) +6 %:
   // beyond ~10k the factorisation is bound by its bulk updates, not by the panel chain, and has no idle tail
   const int nbk = (int)(p->N / DGP_TILE_HOST);
@@ -250,7 +260,11 @@ static void tick(dgp_plan* p, int stage, int stop, hipStream_t s) {
 }
 
 template <typename T>
-__global__ void assemble_kernel(const T* scal, const int* info, long n, int ntheta, int zero_grad, T* out) {
+__global__ void assemble_kernel(const T* scal, const int* info, long n, int ntheta, int zero_grad, T* out, long bs,
+                                long ibs) {
+  scal = site(scal, bs);
+  info = site(info, ibs);
+  out = site(out, (long)DGP_OUT_LEN);
   const int t = threadIdx.x;
   if (t == 0) {
     const T logdet = scal[0], quad = scal[1];
@@ -264,14 +278,24 @@ __global__ void assemble_kernel(const T* scal, const int* info, long n, int nthe
 }
 
 template <typename T>
-__global__ void copy_n_kernel(const T* src, long n, T* dst) {
+__global__ void copy_n_kernel(const T* src, long n, T* dst, long bs) {
+  src = site(src, bs);
+  dst = site(dst, n);
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = src[i];
 }
 
 template <typename T>
+static Batch batch_of(const dgp_plan* p) {
+  Batch bt;
+  bt.B = p->B;
+  bt.ws = (long)(p->site_bytes / sizeof(T));  // layout offsets are multiples of 256 bytes
+  return bt;
+}
+template <typename T>
 static int run_gram(dgp_plan* p, const double* theta, const void* noise, hipStream_t s) {
-  return gram_sym<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)noise, (T*)p->A, s);
+  return gram_sym<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)noise, (T*)p->A, s,
+                     batch_of<T>(p));
 }
 template <typename T>
 static int run_potrf(dgp_plan* p, hipStream_t s) {
@@ -279,25 +303,26 @@ static int run_potrf(dgp_plan* p, hipStream_t s) {
   if (rc) return rc;
   if ((rc = ensure_timing(p))) return rc;
   return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, p->lookahead, s, p->s2, p->ev,
-                  p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop);
+                  p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr,
+                  batch_of<T>(p));
 }
 template <typename T>
 static int run_trtri(dgp_plan* p, hipStream_t s) {
-  return trtri<T>((const T*)p->A, nullptr, p->N, (T*)p->Tm, (T*)p->S /* scratch W aliases S */, s);
+  return trtri<T>((const T*)p->A, nullptr, p->N, (T*)p->Tm, (T*)p->S /* scratch W aliases S */, s, batch_of<T>(p));
 }
 template <typename T>
 static int run_lauum(dgp_plan* p, hipStream_t s) {
-  return lauum<T>((const T*)p->Tm, p->N, (T*)p->S, s);
+  return lauum<T>((const T*)p->Tm, p->N, (T*)p->S, s, batch_of<T>(p));
 }
 template <typename T>
 static int run_solve(dgp_plan* p, const void* r, hipStream_t s) {
   return solve<T>((const T*)p->Tm, p->N, (const T*)r, (int)p->n, (T*)p->z, (T*)p->alpha, (T*)p->spart,
-                  (T*)p->scal + 1, s);
+                  (T*)p->scal + 1, s, batch_of<T>(p));
 }
 template <typename T>
 static int run_grad(dgp_plan* p, const double* theta, void* dtheta, hipStream_t s) {
   return gram_grad<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)p->S, (const T*)p->alpha,
-                      (T*)p->gpart, (T*)dtheta, s);
+                      (T*)p->gpart, (T*)dtheta, s, batch_of<T>(p), DGP_OUT_LEN);
 }
 
 template <typename T>
@@ -312,6 +337,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
   tick(p, TS_POTRF, 0, s);
   const int nbk = (int)(p->N / DGP_TILE_HOST);
   const bool early = early_applies(p) && p->s3 != nullptr;
+  const Batch bt = batch_of<T>(p);
   if (early) {
     // The factorisation's tail is a sequential panel chain that leaves most CUs idle, and the inverse's level
     // recursion only needs the block columns that are already final: issue it piecewise on s3 behind
@@ -372,10 +398,13 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
     tick(p, TS_GRAD, 1, s);
     p->timed_valid = p->timing && p->tev;
     p->have_inverse = 1;
-    if (dnoise && (rc = finish<T>((const T*)p->S, (const T*)p->alpha, p->N, (int)p->n, (T*)dnoise, s))) return rc;
-    if (dr) copy_n_kernel<T><<<(unsigned)((p->n + 255) / 256), 256, 0, s>>>((const T*)p->alpha, p->n, (T*)dr);
+    if (dnoise && (rc = finish<T>((const T*)p->S, (const T*)p->alpha, p->N, (int)p->n, (T*)dnoise, s, bt))) return rc;
+    if (dr)
+      copy_n_kernel<T><<<dim3((unsigned)((p->n + 255) / 256), 1, (unsigned)bt.B), 256, 0, s>>>((const T*)p->alpha, p->n,
+                                                                                           (T*)dr, bt.ws);
   }
-  assemble_kernel<T><<<1, 64, 0, s>>>((const T*)p->scal, p->info, (long)p->n, p->ntheta, !with_grad, (T*)out);
+  assemble_kernel<T><<<dim3(1, 1, (unsigned)bt.B), 64, 0, s>>>((const T*)p->scal, p->info, (long)p->n, p->ntheta, !with_grad,
+                                                             (T*)out, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int));
   p->have_factor = 1;
   return (int)hipGetLastError();
 }
@@ -404,8 +433,8 @@ static int predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, 
   if (rc) return rc;
   if ((rc = gram_diag<T>(p->model, p->d, Xst, M, (int)m, theta, kss, s))) return rc;
   if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, mpad, vpad, s))) return rc;
-  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean);
-  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(vpad, m, (T*)var);
+  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean, 0);
+  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(vpad, m, (T*)var, 0);
   return (int)hipGetLastError();
 }
 
@@ -425,7 +454,7 @@ static int post_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t m,
   if (rc) return rc;
   if ((rc = gram_diag<T>(p->model, p->d, Xst, M, (int)m, theta, kss, s))) return rc;
   if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, mpad, vpad, s))) return rc;
-  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean);
+  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean, 0);
   hipError_t he = hipMemsetAsync(vpad, 0, e * M, s);  // zero "noise" for K(Xs, Xs)
   if (he != hipSuccess) return (int)he;
   if ((rc = gram_sym<T>(p->model, p->d, Xst, M, (int)m, theta, vpad, (T*)cov, s))) return rc;
@@ -470,7 +499,7 @@ static int predict_mean(dgp_plan* p, const double* theta, const void* Xs, int64_
   if (rc) return rc;
   matvec_cols_kernel<T><<<(unsigned)((M + 255) / 256), 256, 0, s>>>((const T*)(w + L.Ks), p->N, M, (int)p->n,
                                                                   (const T*)p->alpha, (T*)(w + L.g));
-  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>((const T*)(w + L.g), m, (T*)mean);
+  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>((const T*)(w + L.g), m, (T*)mean, 0);
   return (int)hipGetLastError();
 }
 
@@ -490,7 +519,7 @@ static int mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m,
   if ((rc = symv_lower<T>((const T*)p->S, p->N, g, (int)p->n, (const T*)p->alpha, beta, (T*)(w + L.spart),
                           (T*)dnoise, s)))                                                   // beta = K^^-1 g
     return rc;
-  if (dr) copy_n_kernel<T><<<(unsigned)((p->n + 255) / 256), 256, 0, s>>>(beta, p->n, (T*)dr);
+  if (dr) copy_n_kernel<T><<<(unsigned)((p->n + 255) / 256), 256, 0, s>>>(beta, p->n, (T*)dr, 0);
   return mean_vjp_grad<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, Xst, M, (int)m, theta, (const T*)p->alpha,
                           beta, (const T*)wts, (T*)(w + L.part), (T*)dtheta, s);
 }
@@ -499,6 +528,8 @@ static int mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m,
 #define DGP_CHECK_PLAN(p)                                                        \
   if (!(p)) return fail(DGP_E_ARG, "null plan");                                 \
   if (!(p)->ws) return fail(DGP_E_WORKSPACE, "plan has no workspace: call dgp_plan_set_workspace")
+#define DGP_SINGLE_SITE(p) \
+  if ((p)->B != 1) return fail(DGP_E_STATE, "batched plans support dgp_set_inputs / dgp_fit_step / dgp_factorize only")
 static int wrap(int rc, const char* where) {
   if (rc > 0) return hipfail((hipError_t)rc, where);
   if (rc < 0) return fail(rc, where);
@@ -511,8 +542,8 @@ int dgp_set_inputs(dgp_plan* p, const void* X, void* stream) {
   DGP_CHECK_PLAN(p);
   if (!X) return fail(DGP_E_ARG, "dgp_set_inputs: null X");
   hipStream_t s = (hipStream_t)stream;
-  int rc = DGP_BY_DTYPE(p, pack_x<double>((const double*)X, (int)p->n, p->d, p->N, (double*)p->Xt, s),
-                        pack_x<float>((const float*)X, (int)p->n, p->d, p->N, (float*)p->Xt, s));
+  int rc = DGP_BY_DTYPE(p, pack_x<double>((const double*)X, (int)p->n, p->d, p->N, (double*)p->Xt, s, batch_of<double>(p)),
+                        pack_x<float>((const float*)X, (int)p->n, p->d, p->N, (float*)p->Xt, s, batch_of<float>(p)));
   p->have_inputs = 1;
   p->have_factor = 0;
   return wrap(rc, "dgp_set_inputs");
@@ -548,6 +579,7 @@ size_t dgp_predict_workspace_bytes(const dgp_plan* p, int64_t m) {
 int dgp_predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
                 void* mean, void* var, void* stream) {
   DGP_CHECK_PLAN(p);
+  DGP_SINGLE_SITE(p);
   if (!theta || !Xs || !work || !mean || !var || m <= 0) return fail(DGP_E_ARG, "dgp_predict: null argument");
   if (!p->have_factor) return fail(DGP_E_STATE, "dgp_predict: no factorisation in the plan (call dgp_factorize)");
   if (work_bytes < dgp_predict_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_predict: workspace too small");
@@ -560,6 +592,7 @@ int dgp_predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, voi
 int dgp_posterior_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
                       void* mean, void* cov, void* stream) {
   DGP_CHECK_PLAN(p);
+  DGP_SINGLE_SITE(p);
   if (!theta || !Xs || !work || !mean || !cov || m <= 0) return fail(DGP_E_ARG, "dgp_posterior_cov: null argument");
   if (!p->have_factor) return fail(DGP_E_STATE, "dgp_posterior_cov: no factorisation in the plan (call dgp_factorize)");
   if (work_bytes < dgp_predict_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_posterior_cov: workspace too small");
@@ -574,6 +607,7 @@ size_t dgp_mean_vjp_workspace_bytes(const dgp_plan* p, int64_t m) { return (p &&
 int dgp_predict_mean(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
                      void* mean, void* stream) {
   DGP_CHECK_PLAN(p);
+  DGP_SINGLE_SITE(p);
   if (!theta || !Xs || !work || !mean || m <= 0) return fail(DGP_E_ARG, "dgp_predict_mean: null argument");
   if (!p->have_factor) return fail(DGP_E_STATE, "dgp_predict_mean: no factorisation in the plan");
   if (work_bytes < dgp_mean_vjp_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_predict_mean: workspace too small");
@@ -585,6 +619,7 @@ int dgp_predict_mean(dgp_plan* p, const double* theta, const void* Xs, int64_t m
 int dgp_mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m, const void* wts, void* work,
                  size_t work_bytes, void* dtheta, void* dr, void* dnoise, void* stream) {
   DGP_CHECK_PLAN(p);
+  DGP_SINGLE_SITE(p);
   if (!theta || !Xs || !wts || !work || !dtheta || m <= 0) return fail(DGP_E_ARG, "dgp_mean_vjp: null argument");
   if (!p->have_factor || !p->have_inverse)
     return fail(DGP_E_STATE, "dgp_mean_vjp: needs K^^-1 and alpha from dgp_fit_step at the same theta");
@@ -662,12 +697,14 @@ int dgp_stage_solve(dgp_plan* p, const void* r, void* stream) {
 }
 int dgp_stage_grad(dgp_plan* p, const double* theta, void* dtheta, void* stream) {
   DGP_CHECK_PLAN(p);
+  DGP_SINGLE_SITE(p);
   if (!theta || !dtheta) return fail(DGP_E_ARG, "dgp_stage_grad: null argument");
   hipStream_t s = (hipStream_t)stream;
   return wrap(DGP_BY_DTYPE(p, run_grad<double>(p, theta, dtheta, s), run_grad<float>(p, theta, dtheta, s)), "dgp_stage_grad");
 }
 int dgp_cross_gram(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* Ks, void* stream) {
   DGP_CHECK_PLAN(p);
+  DGP_SINGLE_SITE(p);
   if (!theta || !Xs || !work || !Ks || m <= 0) return fail(DGP_E_ARG, "dgp_cross_gram: null argument");
   hipStream_t s = (hipStream_t)stream;
   return wrap(DGP_BY_DTYPE(p, cross<double>(p, theta, Xs, m, work, Ks, s), cross<float>(p, theta, Xs, m, work, Ks, s)),

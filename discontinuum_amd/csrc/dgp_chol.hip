@@ -35,7 +35,10 @@ struct Prefetch {
 // A[i,k] <- A[i,k] * L_kk^-T  (L_kk^-1 lives in the diagonal block of Tinv).  This kernel sits on the
 // sequential panel chain, so it uses 64-row tiles: twice the workgroups, half the per-workgroup latency.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T* __restrict__ Tinv, long ld, int k) {
+__global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T* __restrict__ Tinv, long ld, int k,
+                                                      long bs) {
+  A = site(A, bs);
+  Tinv = site(Tinv, bs);
   // 64 rows x all 128 panel columns per workgroup: a workgroup only ever reads the rows it overwrites
   using G = TileGemm<T, true, true, 64, 128>;
   __shared__ T smem[G::SMEM_ELEMS];
@@ -72,7 +75,8 @@ __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg, int nfull,
-                                                      int split) {
+                                                      int split, long bs) {
+  A = site(A, bs);
   __shared__ T smem[TileGemm<T, true, true>::SMEM_ELEMS];
   const int b = (int)blockIdx.x;
   int bi, bj;
@@ -116,13 +120,16 @@ struct SyrkShape {
   }
 };
 
-// the lookahead columns: block columns jcol + blockIdx.z only, 64x64 tiles (latency-critical, see trsm_kernel)
+// the lookahead columns: block columns jcol .. jcol + ncol - 1 only, 64x64 tiles (latency-critical, see trsm_kernel);
+// blockIdx.z = site * ncol + column
 template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int nk, int jcol, int nbk) {
+__global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, long ld, int k, int nk, int jcol, int nbk,
+                                                          int ncol, long bs) {
   using G = TileGemm<T, true, true, 64, 64>;
   __shared__ T smem[G::SMEM_ELEMS];
   __builtin_amdgcn_s_setprio(3);  // panel chain: outrank co-resident bulk-update waves
-  const int jc = jcol + (int)blockIdx.z;
+  A += (long)((int)blockIdx.z / ncol) * bs;
+  const int jc = jcol + (int)blockIdx.z % ncol;
   if ((int)blockIdx.x >= 2 * (nbk - jc)) return;  // the second column is one block shorter
   const long row0 = (long)jc * NB + (long)blockIdx.x * 64;
   const long col0 = (long)jc * NB + (long)blockIdx.y * 64;
@@ -135,7 +142,9 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, lon
 }
 
 template <typename T>
-__global__ void zero1_kernel(T* p, int* info) {
+__global__ void zero1_kernel(T* p, int* info, long bs, long ibs) {
+  p = site(p, bs);
+  info = site(info, ibs);
   if (threadIdx.x == 0) {
     p[0] = T(0);
     info[0] = 0;
@@ -145,7 +154,7 @@ __global__ void zero1_kernel(T* p, int* info) {
 
 // launch the LDS-resident diagonal-block kernel (needs > 64 KB of dynamic LDS: opt in once per type)
 template <typename T>
-static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hipStream_t s) {
+static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hipStream_t s, Batch bt) {
   static bool configured = false;
   const size_t bytes = potrf_diag_fast_smem<T>();
   if (!configured) {
@@ -153,13 +162,14 @@ static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hi
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     configured = true;
   }
-  potrf_diag_fast_kernel<T><<<1, 256, bytes, s>>>(A, N, k0, Tinv, logdet, info);
+  potrf_diag_fast_kernel<T><<<dim3(1, 1, (unsigned)bt.B), 256, bytes, s>>>(A, N, k0, Tinv, logdet, info, bt.ws,
+                                                                           bt.ws * (long)sizeof(T) / (long)sizeof(int));
 }
 
 template <typename T>
 int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
           hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop, int nck, const int* ck_blocks, hipEvent_t* ck_ev,
-          void (*on_ck)(void*, int), void* ck_ctx) {
+          void (*on_ck)(void*, int), void* ck_ctx, Batch bt) {
   const int nbk = (int)(N / NB);
   // checkpoint c: recorded on s once the first ck_blocks[c] block columns of L are final (every schedule records
   // every checkpoint, at the latest when the factorisation is complete)
@@ -173,21 +183,22 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
   };
   int ns = 0;
   double flop = 0.0;
-  zero1_kernel<T><<<1, 64, 0, s>>>(logdet, info);
+  const unsigned Bz = (unsigned)bt.B;
+  zero1_kernel<T><<<dim3(1, 1, Bz), 64, 0, s>>>(logdet, info, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int));
   auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
   const double tile_flop = 2.0 * NB * NB * NB;
   if (!lookahead || nbk < 4 || s2 == nullptr || ev == nullptr) {
     for (int k = 0; k < nbk; ++k) {
-      launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s);
+      launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt);
       if (k + 1 < nbk) {
-        trsm_kernel<T><<<2 * (nbk - k - 1), 256, 0, s>>>(A, Tinv, N, k);
+        trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, Bz), 256, 0, s>>>(A, Tinv, N, k, bt.ws);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
         {
-          const SyrkShape sh((int)tri(nbk - k - 1));
-          syrk_kernel<T><<<sh.grid, 256, 0, s>>>(A, N, k, 1, k + 1, sh.nfull, sh.split);
+          const SyrkShape sh((int)tri(nbk - k - 1), 512 / bt.B);
+          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s>>>(A, N, k, 1, k + 1, sh.nfull, sh.split, bt.ws);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s);
-        flop += tile_flop * tri(nbk - k - 1);
+        flop += tile_flop * tri(nbk - k - 1) * bt.B;
         ++ns;
       }
     }
@@ -196,7 +207,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     if (syrk_flop) *syrk_flop = flop;
     return (int)hipGetLastError();
   }
-  if (lookahead >= 2) {
+  {
     // PAIR-AHEAD schedule.  Pair q = panels (2q, 2q+1).  The chain on stream s factors pair q+1 while the bulk
     // update of pair q runs on s2, so consecutive bulk launches follow each other without waiting for a panel:
     //   chain(q):  [wait U[q-2]]  cols 2q, 2q+1 <- pair q-1 (K=256, one launch)    record P[q-1]
@@ -212,25 +223,26 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     for (int q = 0; q < Q; ++q) {
       const int k0 = 2 * q, ncol = k0 + 1 < nbk ? 2 : 1;
       if (q >= 2) hipStreamWaitEvent(s, U[q - 2], 0);  // bulk(q-2) exists whenever chain(q) does
-      if (q >= 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k0), 2, ncol), 256, 0, s>>>(A, N, k0 - 2, 2, k0, nbk);
+      if (q >= 1)
+        syrk_col_kernel<T><<<dim3(2 * (nbk - k0), 2, ncol * Bz), 256, 0, s>>>(A, N, k0 - 2, 2, k0, nbk, ncol, bt.ws);
       if (q >= 1 && k0 + 2 < nbk) {  // bulk(q-1): columns >= 2q+2 exist
         hipEventRecord(P[q - 1], s);
         hipStreamWaitEvent(s2, P[q - 1], 0);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
         {
-          const SyrkShape sh((int)tri(nbk - k0 - 2));
-          syrk_kernel<T><<<sh.grid, 256, 0, s2>>>(A, N, k0 - 2, 2, k0 + 2, sh.nfull, sh.split);
+          const SyrkShape sh((int)tri(nbk - k0 - 2), 512 / bt.B);
+          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s2>>>(A, N, k0 - 2, 2, k0 + 2, sh.nfull, sh.split, bt.ws);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
-        flop += 2.0 * tile_flop * tri(nbk - k0 - 2);
+        flop += 2.0 * tile_flop * tri(nbk - k0 - 2) * bt.B;
         ++ns;
         hipEventRecord(U[q - 1], s2);
       }
       for (int h = 0; h < ncol; ++h) {
         const int k = k0 + h;
-        if (h == 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2, 1), 256, 0, s>>>(A, N, k0, 1, k, nbk);
-        launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s);
-        if (k + 1 < nbk) trsm_kernel<T><<<2 * (nbk - k - 1), 256, 0, s>>>(A, Tinv, N, k);
+        if (h == 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2, Bz), 256, 0, s>>>(A, N, k0, 1, k, nbk, 1, bt.ws);
+        launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt);
+        if (k + 1 < nbk) trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, Bz), 256, 0, s>>>(A, Tinv, N, k, bt.ws);
         checkpoint(k + 1);
       }
     }
@@ -240,56 +252,6 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     if (syrk_flop) *syrk_flop = flop;
     return (int)hipGetLastError();
   }
-  // One-panel lookahead with PAIRED bulk updates.  Stream s carries the panel chain
-  //     column update (k -> k+1)  ->  diag(k+1)  ->  trsm(k+1)
-  // and stream s2 (lowest priority) the bulk trailing update, launched once per two panels with
-  // K = 256:   after panel k = 2p+1 is ready, panels (2p, 2p+1) update block columns >= 2p+3.
-  // Column 2p+1 gets panel 2p, and column 2p+2 gets panels (2p, 2p+1), from the chain itself.
-  //   P[k]: panel k ready (recorded for odd k)      U[p]: bulk update of pair p done
-  hipEvent_t* P = ev;
-  hipEvent_t* U = ev + nbk;
-  launch_diag<T>(A, N, 0, Tinv, logdet, info, s);
-  trsm_kernel<T><<<2 * (nbk - 1), 256, 0, s>>>(A, Tinv, N, 0);
-  int last_u = -1;
-  for (int k = 0; k + 1 < nbk; ++k) {
-    const bool odd = (k & 1) != 0;
-    const int p = k >> 1;
-    if (odd && k + 2 < nbk) {
-      hipStreamWaitEvent(s2, P[k], 0);
-      if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
-      {
-        const SyrkShape sh((int)tri(nbk - k - 2));
-        syrk_kernel<T><<<sh.grid, 256, 0, s2>>>(A, N, k - 1, 2, k + 2, sh.nfull, sh.split);
-      }
-      if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
-      flop += 2.0 * tile_flop * tri(nbk - k - 2);
-      ++ns;
-      hipEventRecord(U[p], s2);
-    }
-    // column k+1 must carry every earlier pair before the chain adds its own panels: pair p-1 is the last
-    // bulk launch that touches it (pair p starts at column 2p+3 > k+1)
-    if (p >= 1 && last_u < p - 1) {
-      hipStreamWaitEvent(s, U[p - 1], 0);
-      last_u = p - 1;
-    }
-    if (odd) syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k - 1, 2, k + 1, nbk);
-    else syrk_col_kernel<T><<<dim3(2 * (nbk - k - 1), 2), 256, 0, s>>>(A, N, k, 1, k + 1, nbk);
-    launch_diag<T>(A, N, (long)(k + 1) * NB, Tinv, logdet, info, s);
-    if (k + 2 < nbk) {
-      trsm_kernel<T><<<2 * (nbk - k - 2), 256, 0, s>>>(A, Tinv, N, k + 1);
-      if (((k + 1) & 1) != 0 && k + 3 < nbk) hipEventRecord(P[k + 1], s);
-    }
-  }
-  // join: the last bulk launch must precede whatever the caller enqueues next on s
-  {
-    const int kmax = ((nbk - 3) & 1) ? nbk - 3 : nbk - 4;  // largest odd k with k + 2 < nbk
-    const int last_pair = kmax >= 1 ? (kmax - 1) / 2 : -1;
-    if (last_pair >= 0 && last_u < last_pair) hipStreamWaitEvent(s, U[last_pair], 0);
-  }
-  checkpoint(nbk);
-  if (n_syrk) *n_syrk = ns;
-  if (syrk_flop) *syrk_flop = flop;
-  return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -333,10 +295,13 @@ template <typename T, int STEP, int BT, bool QUEUE>
 __global__ __launch_bounds__(256, 2) void trtri_level_kernel(const T* __restrict__ L, T* __restrict__ Tm,
                                                              T* __restrict__ W, long ld, int m, int ntile, int g0,
                                                              int ngroups, int* __restrict__ ctr,
-                                                             const unsigned char* __restrict__ resv) {
+                                                             const unsigned char* __restrict__ resv, long bs) {
   using G = TileGemm<T, true, false, BT, BT>;
   __shared__ T smem[G::SMEM_ELEMS];
   if (!QUEUE) {
+    L = site(L, bs);  // the queue-driven early launches are single-site only
+    Tm = site(Tm, bs);
+    W = site(W, bs);
     const int lo = 2 * m * (g0 + (int)blockIdx.y), mid = lo + m, hi = min(lo + 2 * m, ntile);
     trtri_tile<T, STEP, BT>(L, Tm, W, ld, m, lo, mid, hi, (int)blockIdx.x, smem);
   } else {
@@ -434,7 +399,8 @@ struct EarlyLaunch {
 };
 
 template <typename T, int STEP>
-static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g1, EarlyLaunch* early, hipStream_t s) {
+static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g1, EarlyLaunch* early, hipStream_t s,
+                        Batch bt) {
   if (g1 <= g0) return;
   const int ng = g1 - g0;
   // <= 512 tiles of 128^2 would leave the GPU waiting on the longest one: the small levels use 64^2 tiles
@@ -442,17 +408,19 @@ static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g
   const int m = small ? 2 * mblk : mblk, ntile = (int)(N / (small ? 64 : 128));
   const bool queue = early != nullptr && early->pairs_left > 0 && m * m * ng > early->wg_cap;
   if (!queue) {
-    const dim3 grid((unsigned)(m * m), (unsigned)ng);
-    if (small) trtri_level_kernel<T, STEP, 64, false><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, nullptr, nullptr);
-    else trtri_level_kernel<T, STEP, 128, false><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, nullptr, nullptr);
+    const dim3 grid((unsigned)(m * m), (unsigned)ng, (unsigned)bt.B);
+    if (small)
+      trtri_level_kernel<T, STEP, 64, false><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, nullptr, nullptr, bt.ws);
+    else
+      trtri_level_kernel<T, STEP, 128, false><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, nullptr, nullptr, bt.ws);
     return;
   }
   int* ctr = early->ctr;
   early->ctr += 2;
   --early->pairs_left;
   const unsigned grid = (unsigned)early->wg_cap;
-  if (small) trtri_level_kernel<T, STEP, 64, true><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, ctr, early->resv);
-  else trtri_level_kernel<T, STEP, 128, true><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, ctr, early->resv);
+  if (small) trtri_level_kernel<T, STEP, 64, true><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, ctr, early->resv, 0);
+  else trtri_level_kernel<T, STEP, 128, true><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, ctr, early->resv, 0);
 }
 
 // Launch every step of the level recursion that the first `ready` block columns of L (and the diagonal blocks
@@ -465,12 +433,12 @@ static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g
 // the panel chain; `ctr` = nctr_pairs zeroed (queue, workers) int pairs, `reserve_cus` CUs are left to the chain.
 template <typename T>
 int trtri_advance(const T* L, long N, T* Tm, T* W, int ready, TrtriProgress* st, hipStream_t s, int wg_cap, int* ctr,
-                  int nctr_pairs, int reserve_cus) {
+                  int nctr_pairs, int reserve_cus, Batch bt) {
   const int nbk = (int)(N / NB);
   if (ready > nbk) ready = nbk;
   EarlyLaunch el{wg_cap, ctr + 2 * st->pairs_used, nctr_pairs - st->pairs_used,
                  reserve_cus > 0 ? reserved_cu_table(reserve_cus, nullptr) : nullptr};
-  EarlyLaunch* early = (wg_cap > 0 && ctr != nullptr) ? &el : nullptr;
+  EarlyLaunch* early = (wg_cap > 0 && ctr != nullptr && bt.B == 1) ? &el : nullptr;
   int lvl = 0;
   for (int m = 1; m < nbk && lvl < TrtriProgress::MAXLVL; m *= 2, ++lvl) {
     const int ngroups = (nbk + 2 * m - 1) / (2 * m);
@@ -478,8 +446,8 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready, TrtriProgress* st,
     while (full < ngroups && (2 * m * (full + 1) < nbk ? 2 * m * (full + 1) : nbk) <= ready) ++full;
     int wcan = full;  // groups whose W-step can run
     if (wcan < ngroups && 2 * m * wcan + m <= ready) ++wcan;
-    trtri_level<T, 0>(L, Tm, W, N, m, st->wdone[lvl], wcan, early, s);
-    trtri_level<T, 1>(L, Tm, W, N, m, st->gdone[lvl], full, early, s);
+    trtri_level<T, 0>(L, Tm, W, N, m, st->wdone[lvl], wcan, early, s, bt);
+    trtri_level<T, 1>(L, Tm, W, N, m, st->gdone[lvl], full, early, s, bt);
     if (wcan > st->wdone[lvl]) st->wdone[lvl] = wcan;
     if (full > st->gdone[lvl]) st->gdone[lvl] = full;
   }
@@ -488,15 +456,18 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready, TrtriProgress* st,
 }
 
 template <typename T>
-int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long N, T* Tm, T* W, hipStream_t s) {
+int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long N, T* Tm, T* W, hipStream_t s, Batch bt) {
   TrtriProgress st;
-  return trtri_advance<T>(L, N, Tm, W, (int)(N / NB), &st, s, 0, nullptr, 0, 0);
+  return trtri_advance<T>(L, N, Tm, W, (int)(N / NB), &st, s, 0, nullptr, 0, 0, bt);
 }
 
 // ------------------------------------------------------------------------------------------
 // S[i,j] = sum_{c >= i} T[c,i]^T T[c,j]   (i >= j): K^^-1 = L^-T L^-1
 template <typename T>
-__global__ __launch_bounds__(256, 2) void lauum_kernel(const T* __restrict__ Tm, T* __restrict__ S, long ld, int nbk) {
+__global__ __launch_bounds__(256, 2) void lauum_kernel(const T* __restrict__ Tm, T* __restrict__ S, long ld, int nbk,
+                                                       long bs) {
+  Tm = site(Tm, bs);
+  S = site(S, bs);
   using G = TileGemm<T, false, false>;
   __shared__ T smem[G::SMEM_ELEMS];
   int bi, bj;
@@ -510,9 +481,9 @@ __global__ __launch_bounds__(256, 2) void lauum_kernel(const T* __restrict__ Tm,
 }
 
 template <typename T>
-int lauum(const T* Tm, long N, T* S, hipStream_t s) {
+int lauum(const T* Tm, long N, T* S, hipStream_t s, Batch bt) {
   const int nbk = (int)(N / NB);
-  lauum_kernel<T><<<(unsigned)(nbk * (nbk + 1) / 2), 256, 0, s>>>(Tm, S, N, nbk);
+  lauum_kernel<T><<<dim3((unsigned)(nbk * (nbk + 1) / 2), 1, (unsigned)bt.B), 256, 0, s>>>(Tm, S, N, nbk, bt.ws);
   return (int)hipGetLastError();
 }
 
@@ -520,7 +491,10 @@ int lauum(const T* Tm, long N, T* S, hipStream_t s) {
 // z_i = sum_{j <= i} T[i][j] r_j : one wave per row (coalesced along j)
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ Tm, long ld, const T* __restrict__ r, int n,
-                                                     T* __restrict__ z) {
+                                                     T* __restrict__ z, long bs) {
+  Tm = site(Tm, bs);
+  z = site(z, bs);
+  r = site(r, (long)n);
   const int lane = threadIdx.x & 63;
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long jend = (i / NB + 1) * NB;  // the diagonal block is zero above the diagonal
@@ -535,7 +509,10 @@ __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ Tm, l
 #define DGP_TRMV_CHUNK 512
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_t_kernel(const T* __restrict__ Tm, long ld, const T* __restrict__ z,
-                                                     T* __restrict__ partial) {
+                                                     T* __restrict__ partial, long bs) {
+  Tm = site(Tm, bs);
+  z = site(z, bs);
+  partial = site(partial, bs);
   __shared__ T red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long j = (long)blockIdx.x * 64 + tx;
@@ -550,7 +527,9 @@ __global__ __launch_bounds__(256) void trmv_t_kernel(const T* __restrict__ Tm, l
 
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_t_reduce_kernel(const T* __restrict__ partial, long N, int nchunks,
-                                                            T* __restrict__ alpha) {
+                                                            T* __restrict__ alpha, long bs) {
+  partial = site(partial, bs);
+  alpha = site(alpha, bs);
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= N) return;
   T acc = T(0);
@@ -560,7 +539,9 @@ __global__ __launch_bounds__(256) void trmv_t_reduce_kernel(const T* __restrict_
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ z, long N, T* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ z, long N, T* __restrict__ out, long bs) {
+  z = site(z, bs);
+  out = site(out, bs);
   __shared__ T red[256];
   T acc = T(0);
   for (long i = threadIdx.x; i < N; i += 256) acc += z[i] * z[i];
@@ -626,27 +607,31 @@ int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T
 long solve_partials(long N) { return (N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK * N; }
 
 template <typename T>
-int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T* quad, hipStream_t s) {
-  trmv_n_kernel<T><<<(unsigned)(N / 4), 256, 0, s>>>(Tm, N, r, n, z);
-  sumsq_kernel<T><<<1, 256, 0, s>>>(z, N, quad);
+int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T* quad, hipStream_t s, Batch bt) {
+  const unsigned Bz = (unsigned)bt.B;
+  trmv_n_kernel<T><<<dim3((unsigned)(N / 4), 1, Bz), 256, 0, s>>>(Tm, N, r, n, z, bt.ws);
+  sumsq_kernel<T><<<dim3(1, 1, Bz), 256, 0, s>>>(z, N, quad, bt.ws);
   const int nchunks = (int)((N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK);
-  dim3 grid((unsigned)(N / 64), (unsigned)nchunks);
-  trmv_t_kernel<T><<<grid, 256, 0, s>>>(Tm, N, z, partials);
-  trmv_t_reduce_kernel<T><<<(unsigned)((N + 255) / 256), 256, 0, s>>>(partials, N, nchunks, alpha);
+  dim3 grid((unsigned)(N / 64), (unsigned)nchunks, Bz);
+  trmv_t_kernel<T><<<grid, 256, 0, s>>>(Tm, N, z, partials, bt.ws);
+  trmv_t_reduce_kernel<T><<<dim3((unsigned)((N + 255) / 256), 1, Bz), 256, 0, s>>>(partials, N, nchunks, alpha, bt.ws);
   return (int)hipGetLastError();
 }
 
 // dNLL/dnoise_i = 1/2 (S_ii - alpha_i^2)
 template <typename T>
 __global__ __launch_bounds__(256) void dnoise_kernel(const T* __restrict__ S, const T* __restrict__ alpha, long N,
-                                                     int n, T* __restrict__ dnoise) {
+                                                     int n, T* __restrict__ dnoise, long bs) {
+  S = site(S, bs);
+  alpha = site(alpha, bs);
+  dnoise = site(dnoise, (long)n);
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dnoise[i] = T(0.5) * (S[i * N + i] - alpha[i] * alpha[i]);
 }
 
 template <typename T>
-int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s) {
-  dnoise_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(S, alpha, N, n, dnoise);
+int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s, Batch bt) {
+  dnoise_kernel<T><<<dim3((unsigned)((n + 255) / 256), 1, (unsigned)bt.B), 256, 0, s>>>(S, alpha, N, n, dnoise, bt.ws);
   return (int)hipGetLastError();
 }
 
@@ -723,12 +708,12 @@ int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s) {
   template int posterior_cov<T>(const T*, long, long, T*, hipStream_t);                                          \
   template int symv_lower<T>(const T*, long, const T*, int, const T*, T*, T*, T*, hipStream_t);                  \
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \
-                        const int*, hipEvent_t*, void (*)(void*, int), void*);                                                                                        \
-  template int trtri_advance<T>(const T*, long, T*, T*, int, TrtriProgress*, hipStream_t, int, int*, int, int);                   \
-  template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t);                                          \
-  template int lauum<T>(const T*, long, T*, hipStream_t);                                                        \
-  template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t);                             \
-  template int finish<T>(const T*, const T*, long, int, T*, hipStream_t);                                        \
+                        const int*, hipEvent_t*, void (*)(void*, int), void*, Batch);                                                                                        \
+  template int trtri_advance<T>(const T*, long, T*, T*, int, TrtriProgress*, hipStream_t, int, int*, int, int, Batch);                   \
+  template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t, Batch);                                        \
+  template int lauum<T>(const T*, long, T*, hipStream_t, Batch);                                                      \
+  template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t, Batch);                           \
+  template int finish<T>(const T*, const T*, long, int, T*, hipStream_t, Batch);                                      \
   template int predict_var<T>(const T*, long, const T*, long, T*, const T*, const T*, T*, T*, hipStream_t);
 DGP_INST(double)
 DGP_INST(float)

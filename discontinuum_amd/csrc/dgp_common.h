@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #define DGP_TILE 128  // block size of every blocked algorithm == padding quantum of N
+#define DGP_MAX_BATCH 8  // sites one plan can carry in lockstep (blockIdx.z of every fit-step kernel)
 
 typedef double dgp_d4 __attribute__((ext_vector_type(4)));
 typedef float dgp_f4 __attribute__((ext_vector_type(4)));
@@ -56,6 +57,12 @@ struct Vec16<float> {
   typedef dgp_f4 type;
   static constexpr int N = 4;
 };
+
+// A batched plan keeps B sites' workspaces at a fixed stride: blockIdx.z selects the site.
+template <typename T>
+__device__ __forceinline__ T* site(T* p, long stride) {
+  return p + (long)blockIdx.z * stride;
+}
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

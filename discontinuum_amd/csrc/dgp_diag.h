@@ -152,7 +152,11 @@ __device__ long long dgp_diag_prof[16];
 template <typename T>
 __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A, long ld, long k0,
                                                               T* __restrict__ Tinv, T* __restrict__ logdet,
-                                                              int* __restrict__ info) {
+                                                              int* __restrict__ info, long bs, long ibs) {
+  A = site(A, bs);
+  Tinv = site(Tinv, bs);
+  logdet = site(logdet, bs);
+  info = site(info, ibs);
   extern __shared__ __attribute__((aligned(16))) unsigned char dg_smem[];
   using acc_t = typename Mfma<T>::acc_t;
   // LDS budget (fp64): 36 + 8 sub-blocks of 16x17 + 128 pivots = 96.7 KB.  It has to stay well below

@@ -21,7 +21,10 @@ int model_ntheta(int model, int d) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pack_x_kernel(const T* __restrict__ X, int n, int d, long N, T* __restrict__ Xt) {
+__global__ __launch_bounds__(256) void pack_x_kernel(const T* __restrict__ X, int n, int d, long N, T* __restrict__ Xt,
+                                                     long bs) {
+  X = site(X, (long)n * d);
+  Xt = site(Xt, bs);
   long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   for (int c = 0; c < d; ++c) Xt[(long)c * N + i] = i < n ? X[i * d + c] : T(0);
@@ -66,8 +69,12 @@ __device__ __forceinline__ void load4<float>(const float* src, float (&v)[4]) {
 
 // ------------------------------------------------------------------------------------------
 template <typename T, typename M>
-__global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt, long N, int n, const typename M::Pre pre,
-                                                       const T* __restrict__ noise, T* __restrict__ K) {
+__global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt, long N, int n, const PreBatch<M> pb,
+                                                       const T* __restrict__ noise, T* __restrict__ K, long bs) {
+  const typename M::Pre& pre = pb.p[blockIdx.z];
+  Xt = site(Xt, bs);
+  K = site(K, bs);
+  noise = site(noise, (long)n);
   __shared__ T sfi[M::NF][64], sfj[M::NF][64];
   int bi, bj;
   tri_decode(blockIdx.x, bi, bj);
@@ -154,9 +161,14 @@ __global__ __launch_bounds__(256) void gram_diag_kernel(const T* __restrict__ Xs
 // MODE 0: weights W_ij = S_ij - a_i a_j            (marginal likelihood:  1/2 tr((K^-1 - a a^T) dK))
 // MODE 1: weights W_ij = -(b_i a_j + b_j a_i)       (predictive-mean VJP:  -b^T dK a, symmetrised; S unused)
 template <typename T, typename M, int MODE>
-__global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt, long N, int n, const typename M::Pre pre,
+__global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt, long N, int n, const PreBatch<M> pb,
                                                         const T* __restrict__ S, const T* __restrict__ alpha,
-                                                        const T* __restrict__ beta, T* __restrict__ partials) {
+                                                        const T* __restrict__ beta, T* __restrict__ partials, long bs) {
+  const typename M::Pre& pre = pb.p[blockIdx.z];
+  Xt = site(Xt, bs);
+  if (MODE == 0) S = site(S, bs);
+  alpha = site(alpha, bs);
+  partials = site(partials, bs);
   __shared__ T sfi[M::NF][64], sfj[M::NF][64], sai[64], saj[64], sbi[64], sbj[64];
   __shared__ T red[4][M::NTHETA];
   int bi, bj;
@@ -278,8 +290,10 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ Ks
 // deterministic second stage: one block, fixed summation order
 template <typename T>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ partials, long nblk, int nt,
-                                                          T* __restrict__ out, int accumulate) {
+                                                          T* __restrict__ out, int accumulate, long bs, long os) {
   // one workgroup per hyperparameter; fixed strided order + fixed tree => bitwise reproducible
+  partials = site(partials, bs);
+  out = site(out, os);
   __shared__ T red[256];
   const int p = blockIdx.x;
   T v = T(0);
@@ -315,18 +329,20 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ 
   }
 
 template <typename T>
-int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s) {
-  pack_x_kernel<T><<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(X, n, d, N, Xt);
+int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s, Batch bt) {
+  pack_x_kernel<T><<<dim3((unsigned)((N + 255) / 256), 1, (unsigned)bt.B), dim3(256), 0, s>>>(X, n, d, N, Xt, bt.ws);
   return (int)hipGetLastError();
 }
 
 template <typename T>
-int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s) {
+int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s,
+             Batch bt) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
   const long nb = N / 64;
   const unsigned grid = (unsigned)(nb * (nb + 1) / 2);
-  DGP_DISPATCH_MODEL(model, d, (gram_sym_kernel<T, M><<<dim3(grid), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), noise, K)));
+  DGP_DISPATCH_MODEL(model, d, (gram_sym_kernel<T, M><<<dim3(grid, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
+                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B), noise, K, bt.ws)));
   return (int)hipGetLastError();
 }
 
@@ -356,15 +372,16 @@ long gram_grad_partials(long N) {
 
 template <typename T>
 int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
-              T* partials, T* dtheta, hipStream_t s) {
+              T* partials, T* dtheta, hipStream_t s, Batch bt, long dtheta_stride) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
   const long nb = N / 64;
   const long nblk = nb * (nb + 1) / 2;
   DGP_DISPATCH_MODEL(model, d,
-                     (gram_grad_kernel<T, M, 0><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), S, alpha,
-                                                                                          nullptr, partials)));
-  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0);
+                     (gram_grad_kernel<T, M, 0><<<dim3((unsigned)nblk, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
+                         Xt, N, n, prepare_batch<M>(theta, nt, bt.B), S, alpha, nullptr, partials, bt.ws)));
+  grad_reduce_kernel<T><<<dim3((unsigned)nt, 1, (unsigned)bt.B), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, bt.ws,
+                                                                                 dtheta_stride);
   return (int)hipGetLastError();
 }
 
@@ -377,14 +394,14 @@ int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, lo
   const long nb = N / 64;
   const long nblk = nb * (nb + 1) / 2;
   DGP_DISPATCH_MODEL(model, d,
-                     (gram_grad_kernel<T, M, 1><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), nullptr,
-                                                                                          alpha, beta, partials)));
-  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0);
+                     (gram_grad_kernel<T, M, 1><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(
+                         Xt, N, n, prepare_batch<M>(theta, nt, 1), nullptr, alpha, beta, partials, 0)));
+  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, 0, 0);
   dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64));
   DGP_DISPATCH_MODEL(model, d,
                      (gram_cross_grad_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xt, N, n, Xst, Mp, m, M::prepare(theta), alpha, wts,
                                                                              partials)));
-  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, (long)grid.x * grid.y, nt, dtheta, 1);
+  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, (long)grid.x * grid.y, nt, dtheta, 1, 0, 0);
   return (int)hipGetLastError();
 }
 
@@ -395,11 +412,12 @@ int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream
 }
 
 #define DGP_INST(T)                                                                                              \
-  template int pack_x<T>(const T*, int, int, long, T*, hipStream_t);                                             \
-  template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t);             \
+  template int pack_x<T>(const T*, int, int, long, T*, hipStream_t, Batch);                                      \
+  template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t, Batch);      \
   template int gram_cross<T>(int, int, const T*, long, int, const T*, long, int, const double*, T*, hipStream_t); \
   template int gram_diag<T>(int, int, const T*, long, int, const double*, T*, hipStream_t);                      \
-  template int gram_grad<T>(int, int, const T*, long, int, const double*, const T*, const T*, T*, T*, hipStream_t); \
+  template int gram_grad<T>(int, int, const T*, long, int, const double*, const T*, const T*, T*, T*, hipStream_t, Batch, \
+                            long);                                                                             \
   template int mean_vjp_grad<T>(int, int, const T*, long, int, const T*, long, int, const double*, const T*, const T*, \
                                 const T*, T*, T*, hipStream_t);                                                    \
   template int gemv_rows<T>(const T*, long, long, int, const T*, T*, hipStream_t);

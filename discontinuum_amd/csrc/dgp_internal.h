@@ -8,13 +8,23 @@
 namespace dgp {
 
 inline long round_up(long n, long q) { return (n + q - 1) / q * q; }
+
+// A batched plan carries B <= DGP_MAX_BATCH sites in lockstep: every fit-step kernel is launched once with
+// gridDim.z = B and finds its site's buffers at blockIdx.z * stride (workspace buffers: `ws` elements of the plan's
+// dtype; caller arrays: n or DGP_OUT_LEN).  B = 1 is the plain single-site plan.
+#define DGP_MAX_BATCH_HOST 8  // == DGP_MAX_BATCH in dgp_common.h
+struct Batch {
+  int B = 1;
+  long ws = 0;
+};
 int model_ntheta(int model, int d);  // number of constrained kernel hyperparameters, -1 if unsupported
 
 // ---- dgp_gram.hip ---------------------------------------------------------------------------
 template <typename T>
-int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s);
+int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s, Batch bt = Batch());
 template <typename T>
-int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s);
+int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s,
+             Batch bt = Batch());
 template <typename T>
 int gram_cross(int model, int d, const T* Xt, long N, int n, const T* Xst, long M, int m, const double* theta,
                T* Ks, hipStream_t s);
@@ -22,7 +32,7 @@ template <typename T>
 int gram_diag(int model, int d, const T* Xst, long M, int m, const double* theta, T* kss, hipStream_t s);
 template <typename T>
 int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
-              T* partials, T* dtheta, hipStream_t s);
+              T* partials, T* dtheta, hipStream_t s, Batch bt = Batch(), long dtheta_stride = 0);
 long gram_grad_partials(long N);
 template <typename T>
 int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,
@@ -36,7 +46,7 @@ int potrf(T* A, long N, T* Dinv, T* logdet, int* info, int lookahead, hipStream_
           hipEvent_t* syrk_ev /* 2 per bulk launch, or null */, int* n_syrk, double* syrk_flop,
           int nck = 0, const int* ck_blocks = nullptr /* ascending */, hipEvent_t* ck_ev = nullptr,
           void (*on_ck)(void* ctx, int idx) = nullptr /* called right after checkpoint idx is recorded */,
-          void* ck_ctx = nullptr);
+          void* ck_ctx = nullptr, Batch bt = Batch());
 // progress of the level recursion of trtri when it is issued piecewise (trtri_advance)
 struct TrtriProgress {
   static constexpr int MAXLVL = 16;
@@ -45,7 +55,7 @@ struct TrtriProgress {
 };
 template <typename T>
 int trtri_advance(const T* L, long N, T* Tm, T* W, int ready_blocks, TrtriProgress* st, hipStream_t s, int wg_cap,
-                  int* ctr /* info + EARLY_CTR0, or null */, int nctr_pairs, int reserve_cus);
+                  int* ctr /* info + EARLY_CTR0, or null */, int nctr_pairs, int reserve_cus, Batch bt = Batch());
 // info[0] = potrf status; info[EARLY_CTR0 + 2i ..] = (tile queue, worker count) of the i-th early inverse launch
 #define EARLY_CTR0 4
 #define EARLY_CTR_PAIRS 126
@@ -53,13 +63,14 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready_blocks, TrtriProgre
 // per-device table of compute units kept free of early-inverse workgroups (null if unavailable)
 const unsigned char* reserved_cu_table(int nreserve, int* n_cu);
 template <typename T>
-int trtri(const T* L, const T* Dinv, long N, T* Tm, T* W, hipStream_t s);
+int trtri(const T* L, const T* Dinv, long N, T* Tm, T* W, hipStream_t s, Batch bt = Batch());
 template <typename T>
-int lauum(const T* Tm, long N, T* S, hipStream_t s);
+int lauum(const T* Tm, long N, T* S, hipStream_t s, Batch bt = Batch());
 template <typename T>
-int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T* quad, hipStream_t s);
+int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T* quad, hipStream_t s,
+          Batch bt = Batch());
 template <typename T>
-int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s);
+int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s, Batch bt = Batch());
 template <typename T>
 int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* mean, T* var,
                 hipStream_t s);

@@ -204,4 +204,16 @@ struct Rating {
   }
 };
 
+// hyperparameters of up to DGP_MAX_BATCH sites, passed by value (kernel argument segment); blockIdx.z selects
+template <typename M>
+struct PreBatch {
+  typename M::Pre p[DGP_MAX_BATCH];
+};
+template <typename M>
+inline PreBatch<M> prepare_batch(const double* theta, int ntheta, int B) {
+  PreBatch<M> pb;
+  for (int b = 0; b < DGP_MAX_BATCH; ++b) pb.p[b] = M::prepare(theta + (long)(b < B ? b : 0) * ntheta);
+  return pb;
+}
+
 }  // namespace dgp

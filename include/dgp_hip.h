@@ -68,6 +68,14 @@ int64_t dgp_padded_n(int64_t n);
 int dgp_plan_create(int model, int dtype, int64_t n, int d, dgp_plan** out);
 int dgp_plan_destroy(dgp_plan* plan);
 size_t dgp_plan_workspace_bytes(const dgp_plan* plan);
+/* Optional, before dgp_plan_set_workspace: carry `batch` (1..8) independent sites of the same (model, dtype, n, d)
+ * in lockstep -- every kernel of a fit step is launched once for all of them (gridDim.z = batch), which amortises
+ * the sequential panel chain and the launch rate over the batch (the reference analogue is its map over sites,
+ * examples/nwqn-loadest-example/nwqn-loadest-example.py:156-159).  The workspace grows by the same factor and the
+ * arrays of dgp_set_inputs / dgp_fit_step / dgp_factorize become batch-major: X[batch][n][d], theta[batch][ntheta],
+ * r / noise / dr / dnoise [batch][n], out[batch][DGP_OUT_LEN].  The inference entry points need batch == 1. */
+int dgp_plan_set_batch(dgp_plan* plan, int batch);
+int dgp_plan_batch(const dgp_plan* plan);
 int dgp_plan_set_workspace(dgp_plan* plan, void* dev_ptr, size_t bytes);
 /* Concurrency inside one fit step.  0: everything in order on the caller's stream.  1: the bulk trailing
  * updates of the factorisation run on a second (lowest-priority) stream beside the panel chain.  2 (default):

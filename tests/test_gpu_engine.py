@@ -118,7 +118,8 @@ def test_rating_monotonic_penalty_fit(gpu_device):
 
 
 def test_fit_sites_two_plans_match_sequential(gpu_device):
-    """Config-4 style batches: sites dealt over two plans/streams give the same rows as one plan."""
+    """Config-4 style batches: sites dealt over two plans/streams, or carried by one batched plan, give the same rows
+    as one plan."""
     from discontinuum_amd.backend import GPPlan
     from discontinuum_amd.sites import fit_sites
 
@@ -132,7 +133,10 @@ def test_fit_sites_two_plans_match_sequential(gpu_device):
     one = fit_sites(GPPlan("loadest", n, d, device=dev), [x for x, _ in data], [y for _, y in data], [noise] * 5, theta)
     two = fit_sites([GPPlan("loadest", n, d, device=dev) for _ in range(2)], [x for x, _ in data], [y for _, y in data],
                     [noise] * 5, theta)
+    bat = fit_sites(GPPlan("loadest", n, d, device=dev, lookahead=1, batch=4), [x for x, _ in data], [y for _, y in data],
+                    [noise] * 5, theta)  # 5 sites through a batch of 4: one full chunk and one padded chunk
     torch.cuda.synchronize()
     assert torch.equal(one, two)
+    assert bat.shape == one.shape and (bat - one).abs().max() <= 1e-10 * one.abs().max()
     val, g, _, _ = orc.nll_data_and_grads("loadest", data[3][0].cpu(), data[3][1].cpu(), noise.cpu(), torch.tensor(theta, dtype=torch.float64))
     assert abs(two[3, 0].item() - val.item()) / abs(val.item()) < 1e-10

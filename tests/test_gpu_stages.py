@@ -322,3 +322,38 @@ def test_nan_input_is_reported_not_hidden(gpu_device):
     out, *_ = p.fit_step(theta, r.to(dev), noise.to(dev))
     out = out.cpu()
     assert (not np.isfinite(out[0].item())) or int(out[3]) != 0
+
+
+@pytest.mark.parametrize("model,d,n,B", [("loadest", 3, 700, 3), ("rating", 2, 520, 2), ("loadest", 2, 2300, 4)])
+def test_batched_plan_matches_single_site_plans(model, d, n, B, gpu_device):
+    """A batched plan (B sites in lockstep, one launch per kernel) must give every site what a plan of its own
+    gives: different inputs, hyperparameters, residuals and noise per site; both lookahead levels."""
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev = gpu_device
+    cases = [make_case(model, d, n, seed=20 + b, perturb=0.15) for b in range(B)]
+    X = torch.stack([c[0] for c in cases]).to(dev).contiguous()
+    r = torch.stack([c[1] for c in cases]).to(dev).contiguous()
+    noise = torch.stack([c[2] for c in cases]).to(dev).contiguous()
+    theta = torch.stack([c[3] for c in cases])
+    for level in (1, 0):
+        pb = GPPlan(model, n, d, dtype=torch.float64, device=dev, lookahead=level, batch=B)
+        pb.set_inputs(X)
+        out, dr, dn = pb.fit_step(theta, r, noise)
+        assert out.shape == (B, _lib.OUT_LEN) and dr.shape == (B, n) and dn.shape == (B, n)
+        for b in range(B):
+            p1 = plan_for(model, d, n, cases[b][0], torch.float64, dev, lookahead=level)
+            o1, a1, n1 = p1.fit_step(cases[b][3], r[b].contiguous(), noise[b].contiguous())
+            assert int(out[b, _lib.OUT_INFO]) == 0
+            assert abs(out[b, 0] - o1[0]) <= 1e-12 * abs(o1[0])
+            P = p1.ntheta
+            assert (out[b, 4:4 + P] - o1[4:4 + P]).abs().max() <= 1e-10 * o1[4:4 + P].abs().max()
+            assert (dr[b] - a1).abs().max() <= 1e-10 * a1.abs().max()
+            assert (dn[b] - n1).abs().max() <= 1e-10 * n1.abs().max()
+    # against the oracle for one site, and the single-site-only entry points must refuse a batched plan
+    val, g_theta, g_r, _ = orc.nll_data_and_grads(model, *[cases[B - 1][i] for i in (0, 1, 2, 3)])
+    assert abs(out[B - 1, 0].cpu() - val) <= 1e-10 * abs(val)
+    assert (out[B - 1, 4:4 + g_theta.numel()].cpu() - g_theta).abs().max() <= 1e-8 * max(1.0, g_theta.abs().max().item())
+    with pytest.raises(Exception):
+        pb.predict(theta[0], cases[0][0][:5].to(dev))
