@@ -26,7 +26,7 @@ int run(const char* name) {
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipMemcpy(A, h.data(), ld * ld * sizeof(T), hipMemcpyHostToDevice));
     CK(hipEventRecord(e0));
-    launch_diag<T>(A, ld, 0, Tm, logdet, info, 0);
+    launch_diag<T>(A, ld, 0, Tm, logdet, info, 0, Batch());
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) best = ms;
