@@ -403,8 +403,9 @@ static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g
                         Batch bt) {
   if (g1 <= g0) return;
   const int ng = g1 - g0;
-  // <= 512 tiles of 128^2 would leave the GPU waiting on the longest one: the small levels use 64^2 tiles
-  const bool small = mblk <= 16;
+  // fewer than ~two rounds (1024) of 128^2 tiles would leave the GPU waiting on the longest one: then use 64^2 tiles
+  // (four times as many, at ~87 % of the big tile's rate); a batch multiplies the tile count
+  const bool small = (long)mblk * mblk * ng * bt.B < 1024;
   const int m = small ? 2 * mblk : mblk, ntile = (int)(N / (small ? 64 : 128));
   const bool queue = early != nullptr && early->pairs_left > 0 && m * m * ng > early->wg_cap;
   if (!queue) {
