@@ -24,6 +24,8 @@ struct dgp_plan {
   int model, dtype, d, ntheta;
   int B;                  // sites carried in lockstep (1 = plain plan); site b's buffers sit b * site_bytes further on
   size_t site_bytes;
+  void* pre;              // device scratch for the batch's hyperparameters (B > 8), after the last site
+  int pre_ready;          // the Gram build of the current step has uploaded them
   int64_t n, N;
   size_t elem;
   char* ws;
@@ -137,11 +139,13 @@ int dgp_plan_destroy(dgp_plan* p) {
   return 0;
 }
 
-size_t dgp_plan_workspace_bytes(const dgp_plan* p) { return p ? layout(p).total * (size_t)p->B : 0; }
+size_t dgp_plan_workspace_bytes(const dgp_plan* p) {
+  return p ? layout(p).total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)) : 0;
+}
 
 int dgp_plan_set_batch(dgp_plan* p, int batch) {
   if (!p) return fail(DGP_E_ARG, "null plan");
-  if (batch < 1 || batch > DGP_MAX_BATCH_HOST) return fail(DGP_E_ARG, "dgp_plan_set_batch: batch must be 1..8");
+  if (batch < 1 || batch > DGP_MAX_BATCH_SITES) return fail(DGP_E_ARG, "dgp_plan_set_batch: batch must be 1..1024");
   if (p->ws) return fail(DGP_E_STATE, "dgp_plan_set_batch: call before dgp_plan_set_workspace");
   p->B = batch;
   return 0;
@@ -151,7 +155,8 @@ int dgp_plan_batch(const dgp_plan* p) { return p ? p->B : 0; }
 int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   if (!p || !dev_ptr) return fail(DGP_E_ARG, "dgp_plan_set_workspace: null");
   const Layout L = layout(p);
-  if (bytes < L.total * (size_t)p->B) return fail(DGP_E_WORKSPACE, "dgp_plan_set_workspace: workspace too small");
+  if (bytes < L.total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)))
+    return fail(DGP_E_WORKSPACE, "dgp_plan_set_workspace: workspace too small");
   p->site_bytes = L.total;
   if (((uintptr_t)dev_ptr & 255) != 0) return fail(DGP_E_ARG, "dgp_plan_set_workspace: pointer must be 256-byte aligned");
   p->ws = (char*)dev_ptr;
@@ -166,6 +171,7 @@ int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   p->spart = p->ws + L.spart;
   p->scal = p->ws + L.scal;
   p->info = (int*)(p->ws + L.info);
+  p->pre = pre_scratch_bytes(p->B) ? (void*)(p->ws + L.total * (size_t)p->B) : nullptr;
   p->have_inputs = p->have_factor = 0;
   return 0;
 }
@@ -294,8 +300,9 @@ static Batch batch_of(const dgp_plan* p) {
 }
 template <typename T>
 static int run_gram(dgp_plan* p, const double* theta, const void* noise, hipStream_t s) {
+  p->pre_ready = 1;
   return gram_sym<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)noise, (T*)p->A, s,
-                     batch_of<T>(p));
+                     batch_of<T>(p), p->pre);
 }
 template <typename T>
 static int run_potrf(dgp_plan* p, hipStream_t s) {
@@ -322,7 +329,7 @@ static int run_solve(dgp_plan* p, const void* r, hipStream_t s) {
 template <typename T>
 static int run_grad(dgp_plan* p, const double* theta, void* dtheta, hipStream_t s) {
   return gram_grad<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)p->S, (const T*)p->alpha,
-                      (T*)p->gpart, (T*)dtheta, s, batch_of<T>(p), DGP_OUT_LEN);
+                      (T*)p->gpart, (T*)dtheta, s, batch_of<T>(p), DGP_OUT_LEN, p->pre, p->pre_ready != 0);
 }
 
 template <typename T>

@@ -14,6 +14,8 @@
 
 namespace dgp {
 
+size_t pre_scratch_bytes(int B) { return B > DGP_MAX_BATCH ? (size_t)B * DGP_PRE_SLOT_BYTES : 0; }
+
 int model_ntheta(int model, int d) {
   if (model == DGP_MODEL_LOADEST) return (d >= 2 && d <= 6) ? 2 * d + 5 : -1;
   if (model == DGP_MODEL_RATING) return d == 2 ? 16 : -1;
@@ -71,7 +73,7 @@ __device__ __forceinline__ void load4<float>(const float* src, float (&v)[4]) {
 template <typename T, typename M>
 __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt, long N, int n, const PreBatch<M> pb,
                                                        const T* __restrict__ noise, T* __restrict__ K, long bs) {
-  const typename M::Pre& pre = pb.p[blockIdx.z];
+  const typename M::Pre& pre = pb.get();
   Xt = site(Xt, bs);
   K = site(K, bs);
   noise = site(noise, (long)n);
@@ -164,7 +166,7 @@ template <typename T, typename M, int MODE>
 __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt, long N, int n, const PreBatch<M> pb,
                                                         const T* __restrict__ S, const T* __restrict__ alpha,
                                                         const T* __restrict__ beta, T* __restrict__ partials, long bs) {
-  const typename M::Pre& pre = pb.p[blockIdx.z];
+  const typename M::Pre& pre = pb.get();
   Xt = site(Xt, bs);
   if (MODE == 0) S = site(S, bs);
   alpha = site(alpha, bs);
@@ -336,13 +338,13 @@ int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s, Batch bt) {
 
 template <typename T>
 int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s,
-             Batch bt) {
+             Batch bt, void* pre_scratch) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
   const long nb = N / 64;
   const unsigned grid = (unsigned)(nb * (nb + 1) / 2);
   DGP_DISPATCH_MODEL(model, d, (gram_sym_kernel<T, M><<<dim3(grid, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
-                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B), noise, K, bt.ws)));
+                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, true, s), noise, K, bt.ws)));
   return (int)hipGetLastError();
 }
 
@@ -372,14 +374,15 @@ long gram_grad_partials(long N) {
 
 template <typename T>
 int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
-              T* partials, T* dtheta, hipStream_t s, Batch bt, long dtheta_stride) {
+              T* partials, T* dtheta, hipStream_t s, Batch bt, long dtheta_stride, void* pre_scratch, bool pre_ready) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
   const long nb = N / 64;
   const long nblk = nb * (nb + 1) / 2;
   DGP_DISPATCH_MODEL(model, d,
                      (gram_grad_kernel<T, M, 0><<<dim3((unsigned)nblk, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
-                         Xt, N, n, prepare_batch<M>(theta, nt, bt.B), S, alpha, nullptr, partials, bt.ws)));
+                         Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, !pre_ready, s), S, alpha, nullptr,
+                         partials, bt.ws)));
   grad_reduce_kernel<T><<<dim3((unsigned)nt, 1, (unsigned)bt.B), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, bt.ws,
                                                                                  dtheta_stride);
   return (int)hipGetLastError();
@@ -395,7 +398,7 @@ int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, lo
   const long nblk = nb * (nb + 1) / 2;
   DGP_DISPATCH_MODEL(model, d,
                      (gram_grad_kernel<T, M, 1><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(
-                         Xt, N, n, prepare_batch<M>(theta, nt, 1), nullptr, alpha, beta, partials, 0)));
+                         Xt, N, n, prepare_batch<M>(theta, nt, 1, nullptr, false, s), nullptr, alpha, beta, partials, 0)));
   grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, 0, 0);
   dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64));
   DGP_DISPATCH_MODEL(model, d,
@@ -413,11 +416,11 @@ int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream
 
 #define DGP_INST(T)                                                                                              \
   template int pack_x<T>(const T*, int, int, long, T*, hipStream_t, Batch);                                      \
-  template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t, Batch);      \
+  template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t, Batch, void*); \
   template int gram_cross<T>(int, int, const T*, long, int, const T*, long, int, const double*, T*, hipStream_t); \
   template int gram_diag<T>(int, int, const T*, long, int, const double*, T*, hipStream_t);                      \
   template int gram_grad<T>(int, int, const T*, long, int, const double*, const T*, const T*, T*, T*, hipStream_t, Batch, \
-                            long);                                                                             \
+                            long, void*, bool);                                                                \
   template int mean_vjp_grad<T>(int, int, const T*, long, int, const T*, long, int, const double*, const T*, const T*, \
                                 const T*, T*, T*, hipStream_t);                                                    \
   template int gemv_rows<T>(const T*, long, long, int, const T*, T*, hipStream_t);

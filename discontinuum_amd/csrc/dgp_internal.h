@@ -12,7 +12,8 @@ inline long round_up(long n, long q) { return (n + q - 1) / q * q; }
 // A batched plan carries B <= DGP_MAX_BATCH sites in lockstep: every fit-step kernel is launched once with
 // gridDim.z = B and finds its site's buffers at blockIdx.z * stride (workspace buffers: `ws` elements of the plan's
 // dtype; caller arrays: n or DGP_OUT_LEN).  B = 1 is the plain single-site plan.
-#define DGP_MAX_BATCH_HOST 8  // == DGP_MAX_BATCH in dgp_common.h
+#define DGP_MAX_BATCH_HOST 8     // == DGP_MAX_BATCH in dgp_common.h: hyperparameters by value up to here
+#define DGP_MAX_BATCH_SITES 1024  // largest batch of a plan
 struct Batch {
   int B = 1;
   long ws = 0;
@@ -24,7 +25,7 @@ template <typename T>
 int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s, Batch bt = Batch());
 template <typename T>
 int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s,
-             Batch bt = Batch());
+             Batch bt = Batch(), void* pre_scratch = nullptr /* pre_scratch_bytes(B) of device memory, B > 8 */);
 template <typename T>
 int gram_cross(int model, int d, const T* Xt, long N, int n, const T* Xst, long M, int m, const double* theta,
                T* Ks, hipStream_t s);
@@ -32,7 +33,9 @@ template <typename T>
 int gram_diag(int model, int d, const T* Xst, long M, int m, const double* theta, T* kss, hipStream_t s);
 template <typename T>
 int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
-              T* partials, T* dtheta, hipStream_t s, Batch bt = Batch(), long dtheta_stride = 0);
+              T* partials, T* dtheta, hipStream_t s, Batch bt = Batch(), long dtheta_stride = 0,
+              void* pre_scratch = nullptr, bool pre_ready = false /* gram_sym of this step filled pre_scratch */);
+size_t pre_scratch_bytes(int B);  // device scratch for the hyperparameters of a batch of B (0 up to 8)
 long gram_grad_partials(long N);
 template <typename T>
 int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,

@@ -12,6 +12,7 @@
 // Matern52 (1+sqrt5 r+5r^2/3)exp(-sqrt5 r); Periodic exp(-2 sin^2(pi dx/p)/l).
 // Parameter order = oracle/gp_oracle.py::loadest_gram / rating_gram.
 #pragma once
+#include <vector>
 #include "dgp_common.h"
 
 #define DGP_MAX_THETA 24
@@ -204,15 +205,35 @@ struct Rating {
   }
 };
 
-// hyperparameters of up to DGP_MAX_BATCH sites, passed by value (kernel argument segment); blockIdx.z selects
+// Hyperparameters of a batch, blockIdx.z selects the site: up to DGP_MAX_BATCH sites travel by value in the kernel
+// argument segment (SGPR loads, nothing to upload); larger batches read them from a device array (`dev`) that the
+// launcher fills with one small asynchronous copy per fit step.
 template <typename M>
 struct PreBatch {
   typename M::Pre p[DGP_MAX_BATCH];
+  const typename M::Pre* dev;
+  __device__ __forceinline__ const typename M::Pre& get() const { return dev ? dev[blockIdx.z] : p[blockIdx.z]; }
 };
+// bytes of device scratch a batch of B needs for its hyperparameters (0: they fit the argument segment)
+#define DGP_PRE_SLOT_BYTES 512
+// upload = false reuses what an earlier launcher of the same fit step put into `scratch`
 template <typename M>
-inline PreBatch<M> prepare_batch(const double* theta, int ntheta, int B) {
+inline PreBatch<M> prepare_batch(const double* theta, int ntheta, int B, void* scratch, bool upload, hipStream_t s) {
+  static_assert(sizeof(typename M::Pre) <= DGP_PRE_SLOT_BYTES, "Pre does not fit its scratch slot");
   PreBatch<M> pb;
-  for (int b = 0; b < DGP_MAX_BATCH; ++b) pb.p[b] = M::prepare(theta + (long)(b < B ? b : 0) * ntheta);
+  pb.dev = nullptr;
+  if (B <= DGP_MAX_BATCH || scratch == nullptr) {
+    for (int b = 0; b < DGP_MAX_BATCH; ++b) pb.p[b] = M::prepare(theta + (long)(b < B ? b : 0) * ntheta);
+    return pb;
+  }
+  for (int b = 0; b < DGP_MAX_BATCH; ++b) pb.p[b] = M::prepare(theta);
+  pb.dev = (const typename M::Pre*)scratch;
+  if (upload) {
+    // pageable source: hipMemcpyAsync stages it before returning, so the vector may go out of scope
+    std::vector<typename M::Pre> host((size_t)B);
+    for (int b = 0; b < B; ++b) host[b] = M::prepare(theta + (long)b * ntheta);
+    (void)hipMemcpyAsync(scratch, host.data(), sizeof(typename M::Pre) * (size_t)B, hipMemcpyHostToDevice, s);
+  }
   return pb;
 }
 

@@ -64,7 +64,8 @@ def fit_sites(plans, Xs, rs, noises, theta):
 
     * a BATCHED plan (``GPPlan(..., batch=B)``): B sites per launch in lockstep -- the MI355X-native form of the
       reference's map over sites: the sequential panel chain and the launch rate are amortised over the batch
-      (measured on one MI355X, sites/s: n = 4096 275 -> 623 at B = 8, n = 2048 619 -> 2830, n = 8192 80 -> 101);
+      (measured on one MI355X, sites/s: n = 8192 80 -> 101 and n = 4096 275 -> 623 at B = 8, n = 300 3300 -> 180 000
+      at B = 256);
     * a plain plan, or a list of plain plans for the same (model, n, d): sites are dealt round-robin over them, each
       plan on its own HIP stream (two plans in flight: n = 4096 275 -> 400 sites/s; more add nothing)."""
     if not isinstance(plans, (list, tuple)) and getattr(plans, "batch", 1) > 1:

@@ -68,7 +68,7 @@ int64_t dgp_padded_n(int64_t n);
 int dgp_plan_create(int model, int dtype, int64_t n, int d, dgp_plan** out);
 int dgp_plan_destroy(dgp_plan* plan);
 size_t dgp_plan_workspace_bytes(const dgp_plan* plan);
-/* Optional, before dgp_plan_set_workspace: carry `batch` (1..8) independent sites of the same (model, dtype, n, d)
+/* Optional, before dgp_plan_set_workspace: carry `batch` (1..1024) independent sites of the same (model, dtype, n, d)
  * in lockstep -- every kernel of a fit step is launched once for all of them (gridDim.z = batch), which amortises
  * the sequential panel chain and the launch rate over the batch (the reference analogue is its map over sites,
  * examples/nwqn-loadest-example/nwqn-loadest-example.py:156-159).  The workspace grows by the same factor and the

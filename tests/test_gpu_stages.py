@@ -324,7 +324,8 @@ def test_nan_input_is_reported_not_hidden(gpu_device):
     assert (not np.isfinite(out[0].item())) or int(out[3]) != 0
 
 
-@pytest.mark.parametrize("model,d,n,B", [("loadest", 3, 700, 3), ("rating", 2, 520, 2), ("loadest", 2, 2300, 4)])
+@pytest.mark.parametrize("model,d,n,B", [("loadest", 3, 700, 3), ("rating", 2, 520, 2), ("loadest", 2, 2300, 4),
+                                         ("loadest", 3, 300, 12), ("rating", 2, 200, 20)])  # > 8: hyperparameters via device memory
 def test_batched_plan_matches_single_site_plans(model, d, n, B, gpu_device):
     """A batched plan (B sites in lockstep, one launch per kernel) must give every site what a plan of its own
     gives: different inputs, hyperparameters, residuals and noise per site; both lookahead levels."""
