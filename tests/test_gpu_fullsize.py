@@ -65,3 +65,68 @@ def test_full_size_factor_identities_and_gradient(gpu_device):
     fd = (fp - fm) / (2 * h)
     an = float(grad @ direction)
     assert abs(fd - an) / abs(an) < 1e-6
+
+
+def test_config3_rating_fp32_full_size(gpu_device):
+    """BASELINE config 3: rating-gp kernel, n = 16384, d = 2, fp32 on one GPU.  Size-independent checks in the
+    precision the path computes in: the factor reproduces K^ on probe vectors (rel 2e-5), alpha solves K^ alpha = r
+    (residual rel 5e-2: fp32 against cond(K^) ~ 1e6), the NLL pieces agree with the factor (rel 1e-4)."""
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev = gpu_device
+    n = 16384
+    X, y, yu = orc.synth_rating(n, seed=0)
+    m = orc.RatingOracle.from_stage(torch.tensor(X[:, 1]))
+    raw = torch.zeros(20, dtype=orc.DT)
+    raw[1], raw[2], raw[3] = 1.6, 0.5, -4.0
+    m.clamp_(raw, torch.tensor(X[:, 1]).min())
+    theta = m.constrained(raw)
+    noise = m.noise(raw, n, torch.tensor(yu)).float().to(dev).contiguous()
+    r = (torch.tensor(y) - m.mean(raw, torch.tensor(X))).float().to(dev).contiguous()
+    p = GPPlan("rating", n, 2, dtype=torch.float32, device=dev)
+    p.set_inputs(torch.tensor(X, dtype=torch.float32, device=dev).contiguous())
+    p.stage_gram(theta, noise)
+    K = p.buffer(_lib.BUF_A).clone()
+    V = torch.randn(n, 2, dtype=torch.float32, generator=torch.Generator().manual_seed(3)).to(dev)
+    KV = _sym_matvec(K, V)
+    out, alpha, dnoise = p.fit_step(theta, r, noise)
+    out = out.cpu().double()
+    assert out[_lib.OUT_INFO] == 0 and torch.isfinite(out[:4 + 16]).all()
+    L = torch.tril(p.buffer(_lib.BUF_A))
+    assert (torch.linalg.norm(L @ (L.T @ V) - KV) / torch.linalg.norm(KV)).item() < 2e-5
+    assert (torch.linalg.norm(_sym_matvec(K, alpha[:, None]) - r[:, None]) / torch.linalg.norm(r)).item() < 5e-2
+    logdet = 2.0 * torch.log(torch.diagonal(L).double()).sum().item()
+    quad = float((r.double() * alpha.double()).sum())
+    nll = 0.5 * quad + 0.5 * logdet + 0.5 * n * np.log(2 * np.pi)
+    assert abs(out[_lib.OUT_NLL].item() - nll) / abs(nll) < 1e-4
+
+
+def test_config4_batch_of_sites_full_size(gpu_device):
+    """BASELINE config 4's per-GPU share: independent n = 4096 sites carried by one batched plan (8 per launch).
+    Every site must solve ITS system (K^_b alpha_b = r_b, rel 1e-9) and agree with a plan of its own."""
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev = gpu_device
+    n, d, B = 4096, 3, 8
+    Xs, ys = zip(*[orc.synth_loadest(n, d, seed=100 + b) for b in range(B)])
+    X = torch.tensor(np.stack(Xs), device=dev).contiguous()
+    y = torch.tensor(np.stack(ys), device=dev).contiguous()
+    noise = torch.full((B, n), 0.01, dtype=torch.float64, device=dev)
+    g = torch.Generator().manual_seed(5)
+    theta = orc.positive(0.3 * torch.randn(B, 11, dtype=torch.float64, generator=g))
+    pb = GPPlan("loadest", n, d, device=dev, lookahead=1, batch=B)
+    pb.set_inputs(X)
+    out, alpha, dnoise = pb.fit_step(theta, y, noise)
+    assert out.shape == (B, _lib.OUT_LEN) and bool((out[:, _lib.OUT_INFO] == 0).all())
+    p1 = GPPlan("loadest", n, d, device=dev)
+    for b in (0, B - 1):
+        p1.set_inputs(X[b].contiguous())
+        p1.stage_gram(theta[b], noise[b].contiguous())
+        K = p1.buffer(_lib.BUF_A).clone()
+        res = _sym_matvec(K, alpha[b][:, None]) - y[b][:, None]
+        assert (torch.linalg.norm(res) / torch.linalg.norm(y[b])).item() < 1e-9
+        o1, a1, _ = p1.fit_step(theta[b], y[b].contiguous(), noise[b].contiguous())
+        assert abs(out[b, 0] - o1[0]) <= 1e-12 * abs(o1[0])
+        assert (out[b, 4:15] - o1[4:15]).abs().max() <= 1e-9 * o1[4:15].abs().max()
