@@ -72,7 +72,13 @@ static Layout layout(const dgp_plan* p) {
   return L;
 }
 
-static int default_lookahead() { return 2; }  // the pair-ahead schedule of dgp_chol.hip::potrf
+static int default_lookahead() { return 2; }  // lookahead on: the group-ahead schedule of dgp_chol.hip::potrf
+// panels per group of that schedule: pairs for one site (chain-bound), larger groups (K = 512 bulk updates) for a batch
+static int group_size(int lookahead, int batch) {
+  if (!lookahead) return 0;
+  if (const char* e = getenv("DGP_GROUP")) return atoi(e) < 2 ? 2 : atoi(e);
+  return batch >= 4 ? 4 : 2;
+}
 
 // workgroups the EARLY inverse launches may occupy (one per CU): they share the GPU with the panel chain
 static int early_wg_cap() {
@@ -309,7 +315,7 @@ static int run_potrf(dgp_plan* p, hipStream_t s) {
   int rc = ensure_async(p);
   if (rc) return rc;
   if ((rc = ensure_timing(p))) return rc;
-  return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, p->lookahead, s, p->s2, p->ev,
+  return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B), s, p->s2, p->ev,
                   p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr,
                   batch_of<T>(p));
 }
@@ -372,7 +378,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
       if (rc && !e->rc) e->rc = rc;
     };
     if ((rc = ensure_timing(p))) return rc;
-    rc = potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, p->lookahead, s, p->s2, p->ev,
+    rc = potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B), s, p->s2, p->ev,
                   p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx);
     if (rc || (rc = ctx.rc)) return rc;
     tick(p, TS_POTRF, 1, s);

@@ -208,39 +208,44 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     return (int)hipGetLastError();
   }
   {
-    // PAIR-AHEAD schedule.  Pair q = panels (2q, 2q+1).  The chain on stream s factors pair q+1 while the bulk
-    // update of pair q runs on s2, so consecutive bulk launches follow each other without waiting for a panel:
-    //   chain(q):  [wait U[q-2]]  cols 2q, 2q+1 <- pair q-1 (K=256, one launch)    record P[q-1]
-    //                             diag(2q)  trsm(2q)  col 2q+1 <- panel 2q (K=128)  diag(2q+1)  trsm(2q+1)
-    //   bulk(q-1): [wait P[q-1]]  block columns >= 2q+2 <- pair q-1 (K=256)                     record U[q-1]
-    // Column c gets pairs <= c/2-2 from the bulk launches, pair c/2-1 and its own pair's first panel from the chain.
-    // bulk(q-1) is released only once the chain's two-column update for pair q is through: released together, the
-    // bulk launch takes every CU slot first and that update (the widest chain kernel) runs ~100 us instead of ~20;
-    // the chain, not the bulk stream, is what the first half of the factorisation waits for.
+    // GROUP-AHEAD schedule.  Group q = G consecutive panels (G = 2: pairs, for one site; G = 4 for batched plans,
+    // where the chain is shared by the batch and the bulk update gains from K = 512).  The chain on stream s factors
+    // group q+1 while the bulk update of group q runs on s2, so consecutive bulk launches follow each other without
+    // waiting for a panel:
+    //   chain(q):  [wait U[q-2]]  the G columns of group q <- group q-1 (K = 128 G, one launch)   record P[q-1]
+    //              for each panel k of the group:  column k <- the group's earlier panels (K = 128 h)
+    //                                              diag(k)  trsm(k)
+    //   bulk(q-1): [wait P[q-1]]  block columns >= G(q+1) <- group q-1 (K = 128 G)               record U[q-1]
+    // Column c (group qc) gets groups <= qc-2 from the bulk launches, group qc-1 and its own group's earlier panels
+    // from the chain.  bulk(q-1) is released only once the chain's G-column update for group q is through: released
+    // together, the bulk launch takes every CU slot first and that update (the widest chain kernel) runs ~100 us
+    // instead of ~20; the chain, not the bulk stream, is what the first half of a single site's factorisation
+    // waits for.
+    const int G = lookahead < 2 ? 2 : (lookahead > 8 ? 8 : lookahead);
     hipEvent_t* P = ev;
     hipEvent_t* U = ev + nbk;
-    const int Q = (nbk + 1) / 2;
+    const int Q = (nbk + G - 1) / G;
     for (int q = 0; q < Q; ++q) {
-      const int k0 = 2 * q, ncol = k0 + 1 < nbk ? 2 : 1;
+      const int k0 = G * q, ncol = nbk - k0 < G ? nbk - k0 : G;
       if (q >= 2) hipStreamWaitEvent(s, U[q - 2], 0);  // bulk(q-2) exists whenever chain(q) does
       if (q >= 1)
-        syrk_col_kernel<T><<<dim3(2 * (nbk - k0), 2, ncol * Bz), 256, 0, s>>>(A, N, k0 - 2, 2, k0, nbk, ncol, bt.ws);
-      if (q >= 1 && k0 + 2 < nbk) {  // bulk(q-1): columns >= 2q+2 exist
+        syrk_col_kernel<T><<<dim3(2 * (nbk - k0), 2, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
+      if (q >= 1 && k0 + G < nbk) {  // bulk(q-1): columns >= G(q+1) exist
         hipEventRecord(P[q - 1], s);
         hipStreamWaitEvent(s2, P[q - 1], 0);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
         {
-          const SyrkShape sh((int)tri(nbk - k0 - 2), 512 / bt.B);
-          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s2>>>(A, N, k0 - 2, 2, k0 + 2, sh.nfull, sh.split, bt.ws);
+          const SyrkShape sh((int)tri(nbk - k0 - G), 512 / bt.B);
+          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s2>>>(A, N, k0 - G, G, k0 + G, sh.nfull, sh.split, bt.ws);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
-        flop += 2.0 * tile_flop * tri(nbk - k0 - 2) * bt.B;
+        flop += (double)G * tile_flop * tri(nbk - k0 - G) * bt.B;
         ++ns;
         hipEventRecord(U[q - 1], s2);
       }
       for (int h = 0; h < ncol; ++h) {
         const int k = k0 + h;
-        if (h == 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2, Bz), 256, 0, s>>>(A, N, k0, 1, k, nbk, 1, bt.ws);
+        if (h >= 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2, Bz), 256, 0, s>>>(A, N, k0, h, k, nbk, 1, bt.ws);
         launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt);
         if (k + 1 < nbk) trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, Bz), 256, 0, s>>>(A, Tinv, N, k, bt.ws);
         checkpoint(k + 1);
