@@ -221,7 +221,9 @@ def main():
             stages["trtri_level_kernel"]["flops"] = None
         for v in stages.values():
             v["tflops"] = v["flops"] / (v["ms"] * 1e-3) / 1e12 if (v["flops"] and v["ms"] > 0) else None
-        dom = max(stages, key=lambda k: stages[k]["ms"])
+        # the dominant KERNEL: trtri is a stage of a dozen launches of several kernel instantiations, none of which
+        # outweighs the single lauum launch or the bulk syrk launches (profiles/*_kernel_stats.csv)
+        dom = max(("syrk_kernel", "lauum_kernel"), key=lambda k: stages[k]["ms"])
         ach = stages[dom]["tflops"]
         gram_bytes = N * (N + 64) / 2 * esz + n * d * esz
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
