@@ -16,6 +16,7 @@ F64, F32 = 0, 1
 MODEL_LOADEST, MODEL_RATING = 0, 1
 OUT_NLL, OUT_QUAD, OUT_LOGDET, OUT_INFO, OUT_DTHETA, OUT_LEN = 0, 1, 2, 3, 4, 32
 BUF_XT, BUF_A, BUF_T, BUF_S, BUF_Z, BUF_ALPHA = range(6)
+BUF_SCAL = 7
 TIME_GRAM, TIME_POTRF, TIME_SYRK_SUM, TIME_SYRK_N, TIME_TRTRI, TIME_LAUUM, TIME_SOLVE, TIME_GRAD, TIME_SYRK_FLOP, TIME_COUNT = range(10)
 
 
@@ -45,6 +46,10 @@ SIGNATURES = {
     "dgp_plan_set_lookahead": (_i, [_vp, _i]),
     "dgp_plan_set_batch": (_i, [_vp, _i]),
     "dgp_plan_batch": (_i, [_vp]),
+    "dgp_dist_begin": (_i, [_vp, _vp]),
+    "dgp_dist_factor_group": (_i, [_vp, _i, _i, _vp]),
+    "dgp_dist_update": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "dgp_dist_finish": (_i, [_vp, _vp, C.c_double, _i, _vp, _vp]),
     "dgp_plan_buffer": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64)]),
     "dgp_set_inputs": (_i, [_vp, _vp, _vp]),
     "dgp_fit_step": (_i, [_vp, _dp, _vp, _vp, _vp, _vp, _vp, _vp]),

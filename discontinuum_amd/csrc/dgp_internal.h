@@ -78,6 +78,15 @@ template <typename T>
 int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* mean, T* var,
                 hipStream_t s);
 long solve_partials(long N);
+// ---- one matrix over several GPUs (block-cyclic groups of W panels; see dgp_chol.hip) ----------
+template <typename T>
+int potrf_group(T* A, long N, T* Tinv, T* logdet, int* info, int k0, int W, hipStream_t s);
+template <typename T>
+int syrk_owned(T* A, long N, int k0, int W, int rank, int world, hipStream_t s);
+template <typename T>
+int trsv_lower(const T* L, const T* Tinv /* its diagonal blocks */, long N, const T* r, int n, T* z, T* partials,
+               T* quad, hipStream_t s);
+long trsv_partials(long N);
 template <typename T>
 int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T* partials, T* dnoise, hipStream_t s);
 // cov (M x M) = Kss - V^T V, lower tiles; Kss already holds K(Xs, Xs) (identity pad)

@@ -53,6 +53,7 @@ extern "C" {
 #define DGP_BUF_Z 4     /* L^-1 r */
 #define DGP_BUF_ALPHA 5 /* K^^-1 r */
 #define DGP_BUF_INFO 6  /* int32: info of the last factorisation */
+#define DGP_BUF_SCAL 7  /* scalars: [0] log|K^| accumulated by the diagonal-block kernels, [1] r^T K^^-1 r */
 
 typedef struct dgp_plan dgp_plan;
 
@@ -154,6 +155,19 @@ int dgp_plan_set_timing(dgp_plan* plan, int enabled);
 int dgp_plan_get_timing(dgp_plan* plan, double* ms_out);
 
 /* ---- single stages on the plan buffers, for parity tests and per-kernel profiling ---- */
+/* ONE matrix distributed over `world` GPUs (BASELINE config 5; nothing in the reference).  Every rank owns a full-size
+ * plan; block columns are dealt to the ranks in groups of `nblocks` 128-wide panels, group g to rank g % world.  Per
+ * group: the owner calls dgp_dist_factor_group, the host side broadcasts rows >= 128 first_block of the group's
+ * columns of DGP_BUF_A to the other ranks (torch.distributed / RCCL), then EVERY rank calls dgp_dist_update, which
+ * applies the group's panels to the block columns it owns right of the group.  dgp_dist_begin zeroes the local
+ * log-determinant / info (DGP_BUF_SCAL[0], DGP_BUF_INFO) after dgp_stage_gram; after the last group every rank holds
+ * all of L, and dgp_dist_finish(r, sum of the ranks' log-determinants, max of their infos) solves L z = r by block
+ * rows and writes out[DGP_OUT_NLL / QUAD / LOGDET / INFO].  discontinuum_amd/dist_chol.py drives this. */
+int dgp_dist_begin(dgp_plan* plan, void* stream);
+int dgp_dist_factor_group(dgp_plan* plan, int first_block, int nblocks, void* stream);
+int dgp_dist_update(dgp_plan* plan, int first_block, int nblocks, int rank, int world, void* stream);
+int dgp_dist_finish(dgp_plan* plan, const void* r_dev, double logdet_total, int info_total, void* out_dev, void* stream);
+
 int dgp_stage_gram(dgp_plan* plan, const double* theta_host, const void* noise_dev, void* stream);
 int dgp_stage_potrf(dgp_plan* plan, void* stream);  /* A: K^ -> L ; T diag blocks <- L_kk^-1 */
 int dgp_stage_trtri(dgp_plan* plan, void* stream);  /* T <- L^-1 */
