@@ -48,7 +48,7 @@ SIGNATURES = {
     "dgp_plan_batch": (_i, [_vp]),
     "dgp_dist_begin": (_i, [_vp, _vp]),
     "dgp_dist_factor_group": (_i, [_vp, _i, _i, _vp]),
-    "dgp_dist_update": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "dgp_dist_update": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dgp_dist_finish": (_i, [_vp, _vp, C.c_double, _i, _vp, _vp]),
     "dgp_plan_buffer": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64)]),
     "dgp_set_inputs": (_i, [_vp, _vp, _vp]),

@@ -270,9 +270,10 @@ class GPPlan:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dgp_dist_factor_group(self._h, first_block, nblocks, _stream()), "dgp_dist_factor_group")
 
-    def dist_update(self, first_block: int, nblocks: int, rank: int, world: int):
+    def dist_update(self, first_block: int, nblocks: int, rank: int, world: int, col_begin: int = 0, col_end: int = 0):
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.dgp_dist_update(self._h, first_block, nblocks, rank, world, _stream()), "dgp_dist_update")
+            _lib.check(self.lib.dgp_dist_update(self._h, first_block, nblocks, rank, world, col_begin, col_end, _stream()),
+                       "dgp_dist_update")
 
     def dist_finish(self, r: torch.Tensor, logdet_total: float, info_total: int):
         self._check_vec(r, "r")

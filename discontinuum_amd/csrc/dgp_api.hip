@@ -766,15 +766,17 @@ int dgp_dist_factor_group(dgp_plan* p, int first_block, int nblocks, void* strea
   return wrap(rc, "dgp_dist_factor_group");
 }
 
-int dgp_dist_update(dgp_plan* p, int first_block, int nblocks, int rank, int world, void* stream) {
+int dgp_dist_update(dgp_plan* p, int first_block, int nblocks, int rank, int world, int col_begin, int col_end,
+                    void* stream) {
   DGP_CHECK_PLAN(p);
   DGP_SINGLE_SITE(p);
   const int nbk = (int)(p->N / DGP_TILE_HOST);
   if (first_block < 0 || nblocks < 1 || first_block >= nbk || first_block % nblocks != 0 || world < 1 || rank < 0 || rank >= world)
     return fail(DGP_E_ARG, "dgp_dist_update: bad block range / rank");
   hipStream_t s = (hipStream_t)stream;
-  int rc = DGP_BY_DTYPE(p, syrk_owned<double>((double*)p->A, p->N, first_block, nblocks, rank, world, s),
-                        syrk_owned<float>((float*)p->A, p->N, first_block, nblocks, rank, world, s));
+  if (col_end <= 0) col_end = nbk;
+  int rc = DGP_BY_DTYPE(p, syrk_owned<double>((double*)p->A, p->N, first_block, nblocks, rank, world, col_begin, col_end, s),
+                        syrk_owned<float>((float*)p->A, p->N, first_block, nblocks, rank, world, col_begin, col_end, s));
   return wrap(rc, "dgp_dist_update");
 }
 

@@ -265,7 +265,8 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
 // full-size A but only its own groups are kept up to date.  For group g (owner g % world):
 //     owner:      potrf_group      -- the panel chain of the group's W columns (all rows below)
 //     all ranks:  receive the factored columns (the host side broadcasts rows >= k0 of those columns)
-//     all ranks:  syrk_owned       -- their own block columns right of the group <- the group's panels (K = 128 W)
+//     all ranks:  syrk_owned       -- their own block columns right of the group <- the group's panels (K = 128 W),
+//                                     optionally only those in [jb0, jb1) (lookahead: the next group's columns first)
 // After the last group every rank holds all of L and the inverses of its diagonal blocks (they travel with the
 // panels); the forward solve for the NLL (trsv_lower) needs nothing else.
 template <typename T>
@@ -285,17 +286,17 @@ int potrf_group(T* A, long N, T* Tinv, T* logdet, int* info, int k0, int W, hipS
 // (groups g' = gfirst, gfirst + world, ... of W columns each), blockIdx.x the block rows from the diagonal down
 template <typename T>
 __global__ __launch_bounds__(256, 2) void syrk_owned_kernel(T* __restrict__ A, long ld, int k0, int nk, int W, int nbk,
-                                                            int gfirst, int world) {
+                                                            int gfirst, int world, int jb0, int jb1) {
   __shared__ T smem[TileGemm<T, true, true>::SMEM_ELEMS];
   const int t = (int)blockIdx.y;
   const int bj = (gfirst + (t / W) * world) * W + t % W;
   const int bi = bj + (int)blockIdx.x;
-  if (bj >= nbk || bi >= nbk) return;
+  if (bj >= nbk || bi >= nbk || bj < jb0 || bj >= jb1) return;
   syrk_tile<T, 128, 128>(A, ld, k0, nk, (long)bi * NB, (long)bj * NB, smem);
 }
 
 template <typename T>
-int syrk_owned(T* A, long N, int k0, int W, int rank, int world, hipStream_t s) {
+int syrk_owned(T* A, long N, int k0, int W, int rank, int world, int jb0, int jb1, hipStream_t s) {
   const int nbk = (int)(N / NB);
   const int g = k0 / W;
   int gfirst = g + 1;
@@ -304,7 +305,7 @@ int syrk_owned(T* A, long N, int k0, int W, int rank, int world, hipStream_t s) 
   const int ngroups = (nbk - gfirst * W + world * W - 1) / (world * W);  // owned groups from gfirst on
   const int wk = (k0 + W <= nbk) ? W : nbk - k0;
   syrk_owned_kernel<T><<<dim3((unsigned)(nbk - gfirst * W), (unsigned)(ngroups * W), 1), 256, 0, s>>>(A, N, k0, wk, W, nbk,
-                                                                                                     gfirst, world);
+                                                                                                     gfirst, world, jb0, jb1);
   return (int)hipGetLastError();
 }
 
@@ -838,7 +839,7 @@ int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s) {
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \
                         const int*, hipEvent_t*, void (*)(void*, int), void*, Batch);                                                                                        \
   template int potrf_group<T>(T*, long, T*, T*, int*, int, int, hipStream_t);                                     \
-  template int syrk_owned<T>(T*, long, int, int, int, int, hipStream_t);                                           \
+  template int syrk_owned<T>(T*, long, int, int, int, int, int, int, hipStream_t);                                         \
   template int trsv_lower<T>(const T*, const T*, long, const T*, int, T*, T*, T*, hipStream_t);                             \
   template int trtri_advance<T>(const T*, long, T*, T*, int, TrtriProgress*, hipStream_t, int, int*, int, int, Batch);                   \
   template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t, Batch);                                        \

@@ -82,7 +82,8 @@ long solve_partials(long N);
 template <typename T>
 int potrf_group(T* A, long N, T* Tinv, T* logdet, int* info, int k0, int W, hipStream_t s);
 template <typename T>
-int syrk_owned(T* A, long N, int k0, int W, int rank, int world, hipStream_t s);
+int syrk_owned(T* A, long N, int k0, int W, int rank, int world, int jb0, int jb1 /* owned block columns in [jb0, jb1) */,
+               hipStream_t s);
 template <typename T>
 int trsv_lower(const T* L, const T* Tinv /* its diagonal blocks */, long N, const T* r, int n, T* z, T* partials,
                T* quad, hipStream_t s);

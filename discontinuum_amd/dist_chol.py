@@ -26,40 +26,85 @@ import torch.distributed as dist
 from . import _lib
 
 
-def distributed_nll(plan, theta, r, noise, group_panels: int = 4, group=None):
+def _pack(plan, A, Tm, c0, c1, w):
+    inv = torch.stack([Tm[c:c + 128, c:c + 128] for c in range(c0, c1, 128)])
+    return torch.cat([A[c0:, c0:c1].reshape(-1), inv.reshape(-1)])
+
+
+def _unpack(plan, A, Tm, c0, c1, w, payload):
+    npan = (plan.N - c0) * (c1 - c0)
+    A[c0:, c0:c1].copy_(payload[:npan].view(plan.N - c0, c1 - c0))
+    inv = payload[npan:].view(w, 128, 128)
+    for i, c in enumerate(range(c0, c1, 128)):
+        Tm[c:c + 128, c:c + 128].copy_(inv[i])
+
+
+def distributed_nll(plan, theta, r, noise, group_panels: int = 4, group=None, lookahead: bool = True):
     """-> ``out[32]`` (DGP_OUT_NLL / QUAD / LOGDET / INFO) on every rank.  ``plan`` is this rank's full-size single-site
-    ``GPPlan`` with the (replicated) inputs already set; ``theta``, ``r``, ``noise`` are the same on every rank."""
+    ``GPPlan`` with the (replicated) inputs already set; ``theta``, ``r``, ``noise`` are the same on every rank.
+
+    With ``lookahead`` the owner of group g+1 applies group g to that group's columns FIRST, factors it and starts its
+    broadcast (asynchronous collective) while every rank -- the owner included -- is still applying group g to the
+    rest of its columns; the panel chain and the transfer then hide behind the updates."""
     if plan.batch != 1:
         raise ValueError("distributed_nll needs a plain (unbatched) plan")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     W = int(group_panels)
     nbk = plan.N // 128
+    ngroups = (nbk + W - 1) // W
     plan.stage_gram(theta, noise)
     plan.dist_begin()
     A, Tm = plan.buffer(_lib.BUF_A), plan.buffer(_lib.BUF_T)
-    for g in range((nbk + W - 1) // W):
+
+    def span(g):
         k0 = g * W
         w = min(W, nbk - k0)
+        return k0, w, k0 * 128, (k0 + w) * 128
+
+    def src(g):
         owner = g % world
-        c0, c1 = k0 * 128, (k0 + w) * 128
-        if rank == owner:
-            plan.dist_factor_group(k0, w)
-        if world > 1:
-            # payload: the factored columns from the diagonal down + the inverses of their diagonal blocks
-            npan, ninv = (plan.N - c0) * (c1 - c0), w * 128 * 128
-            if rank == owner:
-                inv = torch.stack([Tm[c:c + 128, c:c + 128] for c in range(c0, c1, 128)])
-                payload = torch.cat([A[c0:, c0:c1].reshape(-1), inv.reshape(-1)])
-            else:
-                payload = torch.empty(npan + ninv, dtype=plan.dtype, device=plan.device)
-            dist.broadcast(payload, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
-            if rank != owner:
-                A[c0:, c0:c1].copy_(payload[:npan].view(plan.N - c0, c1 - c0))
-                inv = payload[npan:].view(w, 128, 128)
-                for i, c in enumerate(range(c0, c1, 128)):
-                    Tm[c:c + 128, c:c + 128].copy_(inv[i])
-        plan.dist_update(k0, W, rank, world)
+        return dist.get_global_rank(group, owner) if group is not None else owner
+
+    def start_broadcast(g):  # collective: every rank calls it; returns (payload, work)
+        k0, w, c0, c1 = span(g)
+        if rank == g % world:
+            payload = _pack(plan, A, Tm, c0, c1, w)
+        else:
+            payload = torch.empty((plan.N - c0) * (c1 - c0) + w * 128 * 128, dtype=plan.dtype, device=plan.device)
+        return payload, dist.broadcast(payload, src=src(g), group=group, async_op=True)
+
+    def finish_broadcast(g, payload, work):
+        work.wait()
+        if rank != g % world:
+            k0, w, c0, c1 = span(g)
+            _unpack(plan, A, Tm, c0, c1, w, payload)
+
+    if rank == 0 % world:
+        plan.dist_factor_group(0, span(0)[1])
+    if world > 1:
+        finish_broadcast(0, *start_broadcast(0))
+    for g in range(ngroups):
+        k0 = g * W
+        nxt = g + 1
+        pending = None
+        if nxt < ngroups and lookahead:
+            if rank == nxt % world:  # bring the next group up to date, factor it
+                plan.dist_update(k0, W, rank, world, nxt * W, min((nxt + 1) * W, nbk))
+                plan.dist_factor_group(nxt * W, span(nxt)[1])
+            if world > 1:
+                pending = start_broadcast(nxt)
+            begin = (nxt + 1) * W if rank == nxt % world else 0
+            plan.dist_update(k0, W, rank, world, begin, 0 if begin < nbk else nbk + 1)
+            if pending is not None:
+                finish_broadcast(nxt, *pending)
+        else:
+            plan.dist_update(k0, W, rank, world)
+            if nxt < ngroups:
+                if rank == nxt % world:
+                    plan.dist_factor_group(nxt * W, span(nxt)[1])
+                if world > 1:
+                    finish_broadcast(nxt, *start_broadcast(nxt))
     stats = torch.tensor([plan.local_logdet(), float(plan.potrf_info())], dtype=torch.float64, device=plan.device)
     if world > 1:
         logdet = stats[:1].clone()

@@ -158,14 +158,19 @@ int dgp_plan_get_timing(dgp_plan* plan, double* ms_out);
 /* ONE matrix distributed over `world` GPUs (BASELINE config 5; nothing in the reference).  Every rank owns a full-size
  * plan; block columns are dealt to the ranks in groups of `nblocks` 128-wide panels, group g to rank g % world.  Per
  * group: the owner calls dgp_dist_factor_group, the host side broadcasts rows >= 128 first_block of the group's
- * columns of DGP_BUF_A to the other ranks (torch.distributed / RCCL), then EVERY rank calls dgp_dist_update, which
+ * columns of DGP_BUF_A (and the inverses of their diagonal blocks, DGP_BUF_T) to the other ranks (torch.distributed /
+ * RCCL), then EVERY rank calls dgp_dist_update, which
  * applies the group's panels to the block columns it owns right of the group.  dgp_dist_begin zeroes the local
  * log-determinant / info (DGP_BUF_SCAL[0], DGP_BUF_INFO) after dgp_stage_gram; after the last group every rank holds
  * all of L, and dgp_dist_finish(r, sum of the ranks' log-determinants, max of their infos) solves L z = r by block
  * rows and writes out[DGP_OUT_NLL / QUAD / LOGDET / INFO].  discontinuum_amd/dist_chol.py drives this. */
 int dgp_dist_begin(dgp_plan* plan, void* stream);
 int dgp_dist_factor_group(dgp_plan* plan, int first_block, int nblocks, void* stream);
-int dgp_dist_update(dgp_plan* plan, int first_block, int nblocks, int rank, int world, void* stream);
+/* col_begin / col_end restrict the update to the owned block columns in [col_begin, col_end) (col_end <= 0: to the
+ * end): the owner of the next group brings that group up to date first, factors it and starts its broadcast while
+ * the rest of the update is still running (lookahead). */
+int dgp_dist_update(dgp_plan* plan, int first_block, int nblocks, int rank, int world, int col_begin, int col_end,
+                    void* stream);
 int dgp_dist_finish(dgp_plan* plan, const void* r_dev, double logdet_total, int info_total, void* out_dev, void* stream);
 
 int dgp_stage_gram(dgp_plan* plan, const double* theta_host, const void* noise_dev, void* stream);

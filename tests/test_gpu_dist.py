@@ -30,7 +30,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, d, W, q):
+def _worker(rank, world, port, n, d, W, lookahead, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,15 +42,17 @@ def _worker(rank, world, port, n, d, W, q):
         X, y, noise, theta = _case(n, d, 7)
         p = GPPlan("loadest", n, d, device=dev)
         p.set_inputs(X.to(dev).contiguous())
-        out = distributed_nll(p, theta, y.to(dev).contiguous(), noise.to(dev).contiguous(), group_panels=W)
+        out = distributed_nll(p, theta, y.to(dev).contiguous(), noise.to(dev).contiguous(), group_panels=W,
+                              lookahead=lookahead)
         torch.cuda.synchronize()
         q.put((rank, out.cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("lookahead", [True, False])
 @pytest.mark.parametrize("n,W", [(300, 1), (1500, 2), (2600, 4), (1000, 3)])
-def test_single_rank_building_blocks(n, W, gpu_device):
+def test_single_rank_building_blocks(n, W, lookahead, gpu_device):
     from discontinuum_amd import _lib
     from discontinuum_amd.backend import GPPlan
     from discontinuum_amd.dist_chol import distributed_nll
@@ -60,20 +62,22 @@ def test_single_rank_building_blocks(n, W, gpu_device):
     p = GPPlan("loadest", n, d, device=dev)
     p.set_inputs(X.to(dev).contiguous())
     ref = p.fit_step(theta, y.to(dev), noise.to(dev))[0].cpu()
-    out = distributed_nll(p, theta, y.to(dev).contiguous(), noise.to(dev).contiguous(), group_panels=W).cpu()
+    out = distributed_nll(p, theta, y.to(dev).contiguous(), noise.to(dev).contiguous(), group_panels=W,
+                          lookahead=lookahead).cpu()
     assert out[_lib.OUT_INFO] == 0
     for k in (_lib.OUT_NLL, _lib.OUT_QUAD, _lib.OUT_LOGDET):
         assert abs(out[k] - ref[k]) <= 1e-11 * abs(ref[k])
 
 
-@pytest.mark.parametrize("world,n,W", [(2, 1500, 2), (3, 2000, 2), (2, 900, 4)])
-def test_ranks_on_one_gpu_match_the_oracle(world, n, W, gpu_device):
+@pytest.mark.parametrize("world,n,W,lookahead", [(2, 1500, 2, True), (3, 2000, 2, True), (2, 900, 4, True), (3, 1300, 1, True),
+                                                  (2, 1500, 2, False)])
+def test_ranks_on_one_gpu_match_the_oracle(world, n, W, lookahead, gpu_device):
     from discontinuum_amd import _lib
 
     d, port = 3, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, d, W, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, d, W, lookahead, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     outs = dict(q.get(timeout=300) for _ in range(world))
