@@ -90,3 +90,18 @@ def test_ranks_on_one_gpu_match_the_oracle(world, n, W, lookahead, gpu_device):
         assert outs[r][_lib.OUT_INFO] == 0
         assert abs(outs[r][_lib.OUT_NLL] - val.item()) <= 1e-10 * abs(val.item())
         assert abs(outs[r][_lib.OUT_NLL] - outs[0][_lib.OUT_NLL]) <= 1e-13 * abs(outs[0][_lib.OUT_NLL])
+
+
+def test_single_rank_fp32(gpu_device):
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+    from discontinuum_amd.dist_chol import distributed_nll
+
+    dev, n, d = gpu_device, 3000, 3
+    X, y, noise, theta = _case(n, d, 11)
+    p = GPPlan("loadest", n, d, dtype=torch.float32, device=dev)
+    p.set_inputs(X.float().to(dev).contiguous())
+    ref = p.fit_step(theta, y.float().to(dev), noise.float().to(dev))[0].cpu()
+    out = distributed_nll(p, theta, y.float().to(dev).contiguous(), noise.float().to(dev).contiguous()).cpu()
+    assert out[_lib.OUT_INFO] == 0
+    assert abs(out[_lib.OUT_NLL] - ref[_lib.OUT_NLL]) <= 1e-4 * abs(ref[_lib.OUT_NLL])

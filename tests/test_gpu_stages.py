@@ -358,3 +358,26 @@ def test_batched_plan_matches_single_site_plans(model, d, n, B, gpu_device):
     assert (out[B - 1, 4:4 + g_theta.numel()].cpu() - g_theta).abs().max() <= 1e-8 * max(1.0, g_theta.abs().max().item())
     with pytest.raises(Exception):
         pb.predict(theta[0], cases[0][0][:5].to(dev))
+
+
+def test_batched_plan_fp32_matches_single_site_plans(gpu_device):
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev, model, d, n, B = gpu_device, "loadest", 3, 900, 5
+    cases = [make_case(model, d, n, seed=60 + b, perturb=0.1) for b in range(B)]
+    X = torch.stack([c[0] for c in cases]).float().to(dev).contiguous()
+    r = torch.stack([c[1] for c in cases]).float().to(dev).contiguous()
+    noise = torch.stack([c[2] for c in cases]).float().to(dev).contiguous()
+    theta = torch.stack([c[3] for c in cases])
+    pb = GPPlan(model, n, d, dtype=torch.float32, device=dev, lookahead=1, batch=B)
+    pb.set_inputs(X)
+    out, dr, dn = pb.fit_step(theta, r, noise)
+    for b in (0, B - 1):
+        p1 = GPPlan(model, n, d, dtype=torch.float32, device=dev, lookahead=1)
+        p1.set_inputs(X[b].contiguous())
+        o1, a1, n1 = p1.fit_step(theta[b], r[b].contiguous(), noise[b].contiguous())
+        assert int(out[b, _lib.OUT_INFO]) == 0
+        # same kernels, same operand order: identical up to the bulk update's tile shapes (fp32 rounding)
+        assert abs(out[b, 0] - o1[0]) <= 1e-5 * abs(o1[0])
+        assert (dr[b] - a1).abs().max() <= 1e-3 * a1.abs().max()
