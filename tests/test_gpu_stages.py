@@ -173,6 +173,32 @@ def test_not_positive_definite_reports_info(gpu_device):
     assert not torch.isfinite(out[_lib.OUT_NLL])
 
 
+@pytest.mark.parametrize("n,level,B", [(2500, 2, 1), (2500, 1, 1), (700, 1, 3)])
+def test_not_positive_definite_every_schedule_terminates(n, level, B, gpu_device):
+    """An indefinite matrix must come back as info >= 1 / non-finite NLL from every schedule -- the early inverse's
+    queue-driven launches and the batched plan included -- and a healthy site in the same batch must be unaffected."""
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev, d = gpu_device, 2
+    X, r, noise, theta = make_case("loadest", d, n, seed=6)
+    bad_noise = torch.full((n,), -0.5, dtype=torch.float64)
+    p = GPPlan("loadest", n, d, device=dev, lookahead=level, batch=B)
+    if B == 1:
+        p.set_inputs(X.to(dev).contiguous())
+        out = p.fit_step(theta, r.to(dev), bad_noise.to(dev))[0].cpu()
+        assert out[_lib.OUT_INFO] >= 1 and not torch.isfinite(out[_lib.OUT_NLL])
+        out = p.fit_step(theta, r.to(dev), noise.to(dev))[0].cpu()  # and the plan recovers on the next call
+        assert out[_lib.OUT_INFO] == 0 and torch.isfinite(out[_lib.OUT_NLL])
+    else:
+        p.set_inputs(X.to(dev).repeat(B, 1, 1).contiguous())
+        nz = torch.stack([noise, bad_noise, noise]).to(dev).contiguous()
+        out = p.fit_step(theta.repeat(B, 1), r.to(dev).repeat(B, 1).contiguous(), nz)[0].cpu()
+        assert out[1, _lib.OUT_INFO] >= 1 and not torch.isfinite(out[1, _lib.OUT_NLL])
+        assert out[0, _lib.OUT_INFO] == 0 and out[2, _lib.OUT_INFO] == 0
+        assert torch.isfinite(out[0, _lib.OUT_NLL]) and out[0, _lib.OUT_NLL] == out[2, _lib.OUT_NLL]
+
+
 def test_bad_arguments_fail_loudly(gpu_device):
     from discontinuum_amd import _lib
     from discontinuum_amd.backend import GPPlan
