@@ -46,6 +46,7 @@ SIGNATURES = {
     "dgp_plan_set_lookahead": (_i, [_vp, _i]),
     "dgp_plan_set_batch": (_i, [_vp, _i]),
     "dgp_plan_batch": (_i, [_vp]),
+    "dgp_plan_set_site_sizes": (_i, [_vp, C.POINTER(C.c_int64), _vp]),
     "dgp_dist_begin": (_i, [_vp, _vp]),
     "dgp_dist_factor_group": (_i, [_vp, _i, _i, _vp]),
     "dgp_dist_update": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),

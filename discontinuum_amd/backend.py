@@ -107,6 +107,15 @@ class GPPlan:
             return flat.view(self.d, N)
         return flat if count == N else flat.view(N, N)
 
+    def set_site_sizes(self, sizes):
+        """Ragged batch: site b uses the first ``sizes[b]`` (<= n) rows of its slots; call before ``set_inputs``."""
+        vals = [int(v) for v in sizes]
+        if len(vals) != self.batch:
+            raise ValueError(f"expected {self.batch} site sizes")
+        arr = (C.c_int64 * self.batch)(*vals)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dgp_plan_set_site_sizes(self._h, arr, _stream()), "dgp_plan_set_site_sizes")
+
     # ------------------------------------------------------------------ hot path
     def set_inputs(self, X: torch.Tensor):
         self._check_vec(X, "X", self.n * self.d)

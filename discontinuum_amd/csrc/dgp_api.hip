@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #include "../../include/dgp_hip.h"
 #include "dgp_common.h"
@@ -26,6 +27,7 @@ struct dgp_plan {
   size_t site_bytes;
   void* pre;              // device scratch for the batch's hyperparameters (B > 8), after the last site
   int pre_ready;          // the Gram build of the current step has uploaded them
+  int* nsite;             // device: the sites' own sizes (B > 1), after the hyperparameter scratch
   int64_t n, N;
   size_t elem;
   char* ws;
@@ -146,7 +148,8 @@ int dgp_plan_destroy(dgp_plan* p) {
 }
 
 size_t dgp_plan_workspace_bytes(const dgp_plan* p) {
-  return p ? layout(p).total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)) : 0;
+  return p ? layout(p).total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)) + (p->B > 1 ? align_up(sizeof(int) * p->B) : 0)
+           : 0;
 }
 
 int dgp_plan_set_batch(dgp_plan* p, int batch) {
@@ -158,10 +161,29 @@ int dgp_plan_set_batch(dgp_plan* p, int batch) {
 }
 int dgp_plan_batch(const dgp_plan* p) { return p ? p->B : 0; }
 
+int dgp_plan_set_site_sizes(dgp_plan* p, const int64_t* sizes, void* stream) {
+  if (!p || !sizes) return fail(DGP_E_ARG, "dgp_plan_set_site_sizes: null argument");
+  if (!p->ws) return fail(DGP_E_WORKSPACE, "plan has no workspace: call dgp_plan_set_workspace");
+  if (p->B == 1) {
+    if (sizes[0] != p->n) return fail(DGP_E_ARG, "dgp_plan_set_site_sizes: an unbatched plan has the size it was created with");
+    return 0;
+  }
+  std::vector<int> v((size_t)p->B);
+  for (int b = 0; b < p->B; ++b) {
+    if (sizes[b] < 1 || sizes[b] > p->n) return fail(DGP_E_ARG, "dgp_plan_set_site_sizes: sizes must be in 1..n");
+    v[b] = (int)sizes[b];
+  }
+  // pageable source: staged before the call returns
+  hipError_t e = hipMemcpyAsync(p->nsite, v.data(), sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(e, "dgp_plan_set_site_sizes");
+  p->have_factor = 0;
+  return 0;
+}
+
 int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   if (!p || !dev_ptr) return fail(DGP_E_ARG, "dgp_plan_set_workspace: null");
   const Layout L = layout(p);
-  if (bytes < L.total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)))
+  if (bytes < dgp_plan_workspace_bytes(p))
     return fail(DGP_E_WORKSPACE, "dgp_plan_set_workspace: workspace too small");
   p->site_bytes = L.total;
   if (((uintptr_t)dev_ptr & 255) != 0) return fail(DGP_E_ARG, "dgp_plan_set_workspace: pointer must be 256-byte aligned");
@@ -178,6 +200,13 @@ int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   p->scal = p->ws + L.scal;
   p->info = (int*)(p->ws + L.info);
   p->pre = pre_scratch_bytes(p->B) ? (void*)(p->ws + L.total * (size_t)p->B) : nullptr;
+  p->nsite = nullptr;
+  if (p->B > 1) {  // every site starts at the full size n
+    p->nsite = (int*)(p->ws + L.total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)));
+    std::vector<int> full((size_t)p->B, (int)p->n);
+    hipError_t e = hipMemcpy(p->nsite, full.data(), sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hipfail(e, "dgp_plan_set_workspace: hipMemcpy");
+  }
   p->have_inputs = p->have_factor = 0;
   return 0;
 }
@@ -274,7 +303,8 @@ static void tick(dgp_plan* p, int stage, int stop, hipStream_t s) {
 
 template <typename T>
 __global__ void assemble_kernel(const T* scal, const int* info, long n, int ntheta, int zero_grad, T* out, long bs,
-                                long ibs) {
+                                long ibs, const int* ns) {
+  n = site_n(ns, (int)n);
   scal = site(scal, bs);
   info = site(info, ibs);
   out = site(out, (long)DGP_OUT_LEN);
@@ -303,6 +333,7 @@ static Batch batch_of(const dgp_plan* p) {
   Batch bt;
   bt.B = p->B;
   bt.ws = (long)(p->site_bytes / sizeof(T));  // layout offsets are multiples of 256 bytes
+  bt.ns = p->nsite;
   return bt;
 }
 template <typename T>
@@ -418,7 +449,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
                                                                                            (T*)dr, bt.ws);
   }
   assemble_kernel<T><<<dim3(1, 1, (unsigned)bt.B), 64, 0, s>>>((const T*)p->scal, p->info, (long)p->n, p->ntheta, !with_grad,
-                                                             (T*)out, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int));
+                                                             (T*)out, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int), bt.ns);
   p->have_factor = 1;
   return (int)hipGetLastError();
 }

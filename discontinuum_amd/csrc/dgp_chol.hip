@@ -620,10 +620,11 @@ int lauum(const T* Tm, long N, T* S, hipStream_t s, Batch bt) {
 // z_i = sum_{j <= i} T[i][j] r_j : one wave per row (coalesced along j)
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ Tm, long ld, const T* __restrict__ r, int n,
-                                                     T* __restrict__ z, long bs) {
+                                                     T* __restrict__ z, long bs, const int* __restrict__ ns) {
   Tm = site(Tm, bs);
   z = site(z, bs);
   r = site(r, (long)n);
+  n = site_n(ns, n);
   const int lane = threadIdx.x & 63;
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long jend = (i / NB + 1) * NB;  // the diagonal block is zero above the diagonal
@@ -738,7 +739,7 @@ long solve_partials(long N) { return (N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK *
 template <typename T>
 int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T* quad, hipStream_t s, Batch bt) {
   const unsigned Bz = (unsigned)bt.B;
-  trmv_n_kernel<T><<<dim3((unsigned)(N / 4), 1, Bz), 256, 0, s>>>(Tm, N, r, n, z, bt.ws);
+  trmv_n_kernel<T><<<dim3((unsigned)(N / 4), 1, Bz), 256, 0, s>>>(Tm, N, r, n, z, bt.ws, bt.ns);
   sumsq_kernel<T><<<dim3(1, 1, Bz), 256, 0, s>>>(z, N, quad, bt.ws);
   const int nchunks = (int)((N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK);
   dim3 grid((unsigned)(N / 64), (unsigned)nchunks, Bz);
@@ -750,17 +751,18 @@ int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T
 // dNLL/dnoise_i = 1/2 (S_ii - alpha_i^2)
 template <typename T>
 __global__ __launch_bounds__(256) void dnoise_kernel(const T* __restrict__ S, const T* __restrict__ alpha, long N,
-                                                     int n, T* __restrict__ dnoise, long bs) {
+                                                     int n, T* __restrict__ dnoise, long bs, const int* __restrict__ ns) {
   S = site(S, bs);
   alpha = site(alpha, bs);
   dnoise = site(dnoise, (long)n);
+  const int nb = site_n(ns, n);
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dnoise[i] = T(0.5) * (S[i * N + i] - alpha[i] * alpha[i]);
+  if (i < n) dnoise[i] = i < nb ? T(0.5) * (S[i * N + i] - alpha[i] * alpha[i]) : T(0);
 }
 
 template <typename T>
 int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s, Batch bt) {
-  dnoise_kernel<T><<<dim3((unsigned)((n + 255) / 256), 1, (unsigned)bt.B), 256, 0, s>>>(S, alpha, N, n, dnoise, bt.ws);
+  dnoise_kernel<T><<<dim3((unsigned)((n + 255) / 256), 1, (unsigned)bt.B), 256, 0, s>>>(S, alpha, N, n, dnoise, bt.ws, bt.ns);
   return (int)hipGetLastError();
 }
 

@@ -63,6 +63,8 @@ template <typename T>
 __device__ __forceinline__ T* site(T* p, long stride) {
   return p + (long)blockIdx.z * stride;
 }
+// a ragged batch: site b uses the first ns[b] <= n rows of its slots, the rest is identity padding like rows >= n
+__device__ __forceinline__ int site_n(const int* ns, int n) { return ns ? ns[blockIdx.z] : n; }
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

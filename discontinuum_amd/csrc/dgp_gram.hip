@@ -24,9 +24,10 @@ int model_ntheta(int model, int d) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_x_kernel(const T* __restrict__ X, int n, int d, long N, T* __restrict__ Xt,
-                                                     long bs) {
+                                                     long bs, const int* __restrict__ ns) {
   X = site(X, (long)n * d);
   Xt = site(Xt, bs);
+  n = site_n(ns, n);
   long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   for (int c = 0; c < d; ++c) Xt[(long)c * N + i] = i < n ? X[i * d + c] : T(0);
@@ -72,11 +73,13 @@ __device__ __forceinline__ void load4<float>(const float* src, float (&v)[4]) {
 // ------------------------------------------------------------------------------------------
 template <typename T, typename M>
 __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt, long N, int n, const PreBatch<M> pb,
-                                                       const T* __restrict__ noise, T* __restrict__ K, long bs) {
+                                                       const T* __restrict__ noise, T* __restrict__ K, long bs,
+                                                       const int* __restrict__ ns) {
   const typename M::Pre& pre = pb.get();
   Xt = site(Xt, bs);
   K = site(K, bs);
   noise = site(noise, (long)n);
+  n = site_n(ns, n);
   __shared__ T sfi[M::NF][64], sfj[M::NF][64];
   int bi, bj;
   tri_decode(blockIdx.x, bi, bj);
@@ -165,7 +168,9 @@ __global__ __launch_bounds__(256) void gram_diag_kernel(const T* __restrict__ Xs
 template <typename T, typename M, int MODE>
 __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt, long N, int n, const PreBatch<M> pb,
                                                         const T* __restrict__ S, const T* __restrict__ alpha,
-                                                        const T* __restrict__ beta, T* __restrict__ partials, long bs) {
+                                                        const T* __restrict__ beta, T* __restrict__ partials, long bs,
+                                                        const int* __restrict__ ns) {
+  n = site_n(ns, n);
   const typename M::Pre& pre = pb.get();
   Xt = site(Xt, bs);
   if (MODE == 0) S = site(S, bs);
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ 
 
 template <typename T>
 int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s, Batch bt) {
-  pack_x_kernel<T><<<dim3((unsigned)((N + 255) / 256), 1, (unsigned)bt.B), dim3(256), 0, s>>>(X, n, d, N, Xt, bt.ws);
+  pack_x_kernel<T><<<dim3((unsigned)((N + 255) / 256), 1, (unsigned)bt.B), dim3(256), 0, s>>>(X, n, d, N, Xt, bt.ws, bt.ns);
   return (int)hipGetLastError();
 }
 
@@ -344,7 +349,7 @@ int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, 
   const long nb = N / 64;
   const unsigned grid = (unsigned)(nb * (nb + 1) / 2);
   DGP_DISPATCH_MODEL(model, d, (gram_sym_kernel<T, M><<<dim3(grid, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
-                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, true, s), noise, K, bt.ws)));
+                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, true, s), noise, K, bt.ws, bt.ns)));
   return (int)hipGetLastError();
 }
 
@@ -382,7 +387,7 @@ int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta,
   DGP_DISPATCH_MODEL(model, d,
                      (gram_grad_kernel<T, M, 0><<<dim3((unsigned)nblk, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
                          Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, !pre_ready, s), S, alpha, nullptr,
-                         partials, bt.ws)));
+                         partials, bt.ws, bt.ns)));
   grad_reduce_kernel<T><<<dim3((unsigned)nt, 1, (unsigned)bt.B), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, bt.ws,
                                                                                  dtheta_stride);
   return (int)hipGetLastError();
@@ -398,7 +403,7 @@ int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, lo
   const long nblk = nb * (nb + 1) / 2;
   DGP_DISPATCH_MODEL(model, d,
                      (gram_grad_kernel<T, M, 1><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(
-                         Xt, N, n, prepare_batch<M>(theta, nt, 1, nullptr, false, s), nullptr, alpha, beta, partials, 0)));
+                         Xt, N, n, prepare_batch<M>(theta, nt, 1, nullptr, false, s), nullptr, alpha, beta, partials, 0, nullptr)));
   grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, 0, 0);
   dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64));
   DGP_DISPATCH_MODEL(model, d,

@@ -17,6 +17,7 @@ inline long round_up(long n, long q) { return (n + q - 1) / q * q; }
 struct Batch {
   int B = 1;
   long ws = 0;
+  const int* ns = nullptr;  // device array of the sites' own sizes n_b <= n (ragged batch), or null: all n
 };
 int model_ntheta(int model, int d);  // number of constrained kernel hyperparameters, -1 if unsupported
 

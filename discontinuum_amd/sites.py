@@ -43,15 +43,26 @@ def gather_site_results(local: torch.Tensor, n_sites: int, group=None) -> torch.
 
 
 def _fit_sites_batched(plan, Xs, rs, noises, theta):
-    """Chunks of ``plan.batch`` sites per launch; a short last chunk is padded by repeating its last site."""
-    B, rows = plan.batch, []
+    """Chunks of ``plan.batch`` sites per launch; sites may have fewer observations than the plan's n (ragged batch:
+    their slots are zero-padded and ``set_site_sizes`` tells the kernels); a short last chunk repeats its last site."""
+    B, n, rows = plan.batch, plan.n, []
     th = torch.as_tensor(theta, dtype=torch.float64).reshape(1, -1)
+
+    def slot(t, width=None):  # one site's array in an n-row slot
+        if t.shape[0] == n:
+            return t
+        if t.shape[0] > n:
+            raise ValueError(f"a site has {t.shape[0]} observations but the plan holds {n}")
+        pad = torch.zeros((n - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        return torch.cat([t, pad])
+
     for lo in range(0, len(Xs), B):
         idx = list(range(lo, min(lo + B, len(Xs))))
         pad = idx + [idx[-1]] * (B - len(idx))
-        plan.set_inputs(torch.stack([Xs[i] for i in pad]).contiguous())
-        out = plan.fit_step(th.repeat(B, 1), torch.stack([rs[i] for i in pad]).contiguous(),
-                            torch.stack([noises[i] for i in pad]).contiguous())[0]
+        plan.set_site_sizes([Xs[i].shape[0] for i in pad])
+        plan.set_inputs(torch.stack([slot(Xs[i]) for i in pad]).contiguous())
+        out = plan.fit_step(th.repeat(B, 1), torch.stack([slot(rs[i]) for i in pad]).contiguous(),
+                            torch.stack([slot(noises[i]) for i in pad]).contiguous())[0]
         rows.append(out[: len(idx)])
     if not rows:
         return torch.empty(0, 32, dtype=plan.dtype, device=plan.device)
@@ -64,8 +75,8 @@ def fit_sites(plans, Xs, rs, noises, theta):
 
     * a BATCHED plan (``GPPlan(..., batch=B)``): B sites per launch in lockstep -- the MI355X-native form of the
       reference's map over sites: the sequential panel chain and the launch rate are amortised over the batch
-      (measured on one MI355X, sites/s: n = 8192 80 -> 101 and n = 4096 275 -> 623 at B = 8, n = 300 3300 -> 180 000
-      at B = 256);
+      (measured on one MI355X, sites/s: n = 8192 80 -> 103 and n = 4096 275 -> 623 at B = 8, n = 300 3300 -> 180 000
+      at B = 256); sites may have FEWER observations than the plan's n (ragged batch);
     * a plain plan, or a list of plain plans for the same (model, n, d): sites are dealt round-robin over them, each
       plan on its own HIP stream (two plans in flight: n = 4096 275 -> 400 sites/s; more add nothing)."""
     if not isinstance(plans, (list, tuple)) and getattr(plans, "batch", 1) > 1:

@@ -77,6 +77,10 @@ size_t dgp_plan_workspace_bytes(const dgp_plan* plan);
  * r / noise / dr / dnoise [batch][n], out[batch][DGP_OUT_LEN].  The inference entry points need batch == 1. */
 int dgp_plan_set_batch(dgp_plan* plan, int batch);
 int dgp_plan_batch(const dgp_plan* plan);
+/* Ragged batches (after dgp_plan_set_workspace, before dgp_set_inputs): site b has sizes[b] <= n observations; it
+ * uses the first sizes[b] rows of its [n]-sized slots in X / r / noise (the rest is ignored), its padding is handled
+ * like the plan's own (identity), its NLL carries sizes[b]/2 log(2 pi), and dr / dnoise are zero beyond sizes[b]. */
+int dgp_plan_set_site_sizes(dgp_plan* plan, const int64_t* sizes_host, void* stream);
 int dgp_plan_set_workspace(dgp_plan* plan, void* dev_ptr, size_t bytes);
 /* Concurrency inside one fit step.  0: everything in order on the caller's stream.  1: the bulk trailing
  * updates of the factorisation run on a second (lowest-priority) stream beside the panel chain.  2 (default):

@@ -138,5 +138,13 @@ def test_fit_sites_two_plans_match_sequential(gpu_device):
     torch.cuda.synchronize()
     assert torch.equal(one, two)
     assert bat.shape == one.shape and (bat - one).abs().max() <= 1e-10 * one.abs().max()
+    # ragged sites through the same batched plan: each row must match a plan of that site's own size
+    sizes = [600, 433, 600, 128, 57]
+    rag = fit_sites(GPPlan("loadest", n, d, device=dev, lookahead=1, batch=4), [x[:k] for (x, _), k in zip(data, sizes)],
+                    [y[:k] for (_, y), k in zip(data, sizes)], [noise[:k] for k in sizes], theta)
+    for i in (1, 3, 4):
+        solo = fit_sites(GPPlan("loadest", sizes[i], d, device=dev), [data[i][0][:sizes[i]]], [data[i][1][:sizes[i]]],
+                         [noise[:sizes[i]]], theta)
+        assert (rag[i] - solo[0]).abs().max() <= 1e-9 * solo[0].abs().max()
     val, g, _, _ = orc.nll_data_and_grads("loadest", data[3][0].cpu(), data[3][1].cpu(), noise.cpu(), torch.tensor(theta, dtype=torch.float64))
     assert abs(two[3, 0].item() - val.item()) / abs(val.item()) < 1e-10

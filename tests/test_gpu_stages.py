@@ -407,3 +407,39 @@ def test_batched_plan_fp32_matches_single_site_plans(gpu_device):
         # same kernels, same operand order: identical up to the bulk update's tile shapes (fp32 rounding)
         assert abs(out[b, 0] - o1[0]) <= 1e-5 * abs(o1[0])
         assert (dr[b] - a1).abs().max() <= 1e-3 * a1.abs().max()
+
+
+@pytest.mark.parametrize("model,d,sizes", [("loadest", 3, [700, 513, 300, 129]), ("rating", 2, [400, 400, 77]),
+                                           ("loadest", 2, [2300, 1000, 2299])])
+def test_ragged_batch_matches_plans_of_each_size(model, d, sizes, gpu_device):
+    """Sites with different numbers of observations in one batched plan: site b uses the first sizes[b] rows of its
+    slots (the unused tails are filled with NaN here to prove they are never read) and must match a plan of size
+    sizes[b]."""
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev, B, n = gpu_device, len(sizes), max(sizes)
+    cases = [make_case(model, d, nb, seed=80 + b, perturb=0.1) for b, nb in enumerate(sizes)]
+    X = torch.full((B, n, d), float("nan"), dtype=torch.float64)
+    r = torch.full((B, n), float("nan"), dtype=torch.float64)
+    noise = torch.full((B, n), float("nan"), dtype=torch.float64)
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        X[b, :nb], r[b, :nb], noise[b, :nb] = c[0], c[1], c[2]
+    theta = torch.stack([c[3] for c in cases])
+    pb = GPPlan(model, n, d, device=dev, lookahead=1, batch=B)
+    pb.set_site_sizes(sizes)
+    pb.set_inputs(X.to(dev).contiguous())
+    out, dr, dn = pb.fit_step(theta, r.to(dev).contiguous(), noise.to(dev).contiguous())
+    out, dr, dn = out.cpu(), dr.cpu(), dn.cpu()
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        p1 = plan_for(model, d, nb, c[0], torch.float64, dev, lookahead=1)
+        o1, a1, n1 = [t.cpu() for t in p1.fit_step(c[3], c[1].to(dev), c[2].to(dev))]
+        assert int(out[b, _lib.OUT_INFO]) == 0
+        assert abs(out[b, 0] - o1[0]) <= 1e-11 * abs(o1[0])
+        P = p1.ntheta
+        assert (out[b, 4:4 + P] - o1[4:4 + P]).abs().max() <= 1e-9 * max(1.0, o1[4:4 + P].abs().max().item())
+        assert (dr[b, :nb] - a1).abs().max() <= 1e-9 * a1.abs().max()
+        assert (dn[b, :nb] - n1).abs().max() <= 1e-9 * n1.abs().max()
+        assert bool((dr[b, nb:] == 0).all()) and bool((dn[b, nb:] == 0).all())
+    with pytest.raises(Exception):
+        pb.set_site_sizes([n + 1] + sizes[1:])
