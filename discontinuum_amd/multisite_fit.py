@@ -1,0 +1,216 @@
+"""Train MANY sites at once on one GPU: ``fit_many``.
+
+The reference trains one site per process (``model.fit`` inside a cloud map,
+``examples/nwqn-loadest-example/nwqn-loadest-example.py:120-159``).  Here the sites share one batched device plan
+(``GPPlan(batch=B)``, ragged sizes allowed): every training iteration is ONE batched fit step on the GPU and ONE
+vectorised evaluation of the host-side algebra (constraints, priors, the constant mean) over all sites
+(``torch.func.vmap`` over the stacked parameters of the per-site models), followed by the reference's optimiser
+step applied per site:
+
+* Adam(lr, betas (0.9, 0.999), eps 1e-8, weight_decay 1e-4)            (``engines/gpytorch.py:268-286``)
+* gradient clipping to norm 1.0 PER SITE                                 (``:387``)
+* ReduceLROnPlateau(min, factor 0.7, patience max(20, patience // 2), threshold 1e-4 rel, cooldown 10, min_lr 1e-6)
+  PER SITE                                                               (``:296-305``)
+* an iteration whose objective is NaN / Inf (or whose matrix is not positive definite) is skipped for that site,
+  more than 10 in a row raise                                            (``:352-379``)
+
+so each site follows the trajectory ``model.fit`` would give it (tests/test_gpu_engine.py compares them).  Afterwards
+every model holds its fitted parameters and is ready for ``predict``.  Scope: models whose host side is plain
+elementwise torch (loadest-gp); rating-gp's mean clamps parameters in place per call and stays on ``model.fit``.
+Not supported here: early stopping, resume, penalty callbacks, AdamW.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+from torch.func import functional_call, vmap
+
+from . import _lib
+from .backend import GPPlan
+from .gp.kernels import prior_closures
+from .gp.lowering import lower
+
+
+class _HostSide(nn.Module):
+    """theta (P,), log-prior, constant mean of ONE site as a function of its module parameters."""
+
+    def __init__(self, model, likelihood, d):
+        super().__init__()
+        self.model = model
+        self.name, self._theta = lower(model.covar_module, d)
+        self._priors = prior_closures(model)
+        if likelihood is not None and not any(likelihood is m for m in model.modules()):
+            self.likelihood = likelihood
+            self._priors += prior_closures(likelihood)
+
+    def forward(self):
+        lp = torch.zeros((), dtype=torch.float64)
+        for prior, closure, mod in self._priors:
+            lp = lp + prior.log_prob(closure(mod)).sum()
+        return self._theta(), lp, self.model.mean_module.constant.reshape(())
+
+
+class _BatchedNLL(torch.autograd.Function):
+    """Data terms of B sites from one batched ``dgp_fit_step``; sites that fail come back as NaN with zero gradient."""
+
+    @staticmethod
+    def forward(ctx, plan, theta, r, noise):
+        out, dr, _dnoise = plan.fit_step(theta, r, noise)
+        host = out.to("cpu", torch.float64)
+        ok = (host[:, _lib.OUT_INFO] == 0) & torch.isfinite(host[:, _lib.OUT_NLL])
+        dtheta = torch.nan_to_num(host[:, _lib.OUT_DTHETA:_lib.OUT_DTHETA + plan.ntheta], nan=0.0, posinf=0.0, neginf=0.0)
+        dtheta = dtheta * ok[:, None]
+        dr = torch.nan_to_num(dr, nan=0.0, posinf=0.0, neginf=0.0) * ok.to(dr.device)[:, None]
+        ctx.save_for_backward(dtheta, dr)
+        ctx.theta_dtype = theta.dtype
+        return torch.where(ok, host[:, _lib.OUT_NLL], torch.full_like(host[:, 0], float("nan")))
+
+    @staticmethod
+    def backward(ctx, g):
+        dtheta, dr = ctx.saved_tensors
+        g = torch.nan_to_num(g, nan=0.0)
+        return None, (dtheta * g[:, None]).to(ctx.theta_dtype), dr * g.to(dr.device, dr.dtype)[:, None], None
+
+
+def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.05, patience: int = 60,
+             scheduler: bool = True, progress: bool = False):
+    """Fit ``models[i]`` to ``datasets[i] = (covariates, target)`` for all i at once.  Returns the per-site final
+    objectives (a float64 tensor); the models are updated in place (``is_fitted``, parameters, device state)."""
+    if len(models) != len(datasets) or not models:
+        raise ValueError("fit_many needs one (covariates, target) pair per model")
+    B = len(models)
+    dtype, device = models[0].dtype, torch.device(models[0].device)
+    xs, ys, hosts = [], [], []
+    for m, (cov, tgt) in zip(models, datasets):
+        m.dm.fit(target=tgt, covariates=cov, target_unc=None)
+        m.X, m.y = m.dm.X, m.dm.y
+        tx, ty = torch.tensor(m.X, dtype=dtype), torch.tensor(m.y, dtype=dtype)
+        m.model = m.build_model(tx, ty)
+        if hasattr(m.model, "prepare_eval") or not hasattr(m.model.mean_module, "constant"):
+            raise NotImplementedError("fit_many supports models with a constant mean (loadest-gp); use model.fit")
+        m.model.train()
+        m.likelihood.train()
+        xs.append(tx)
+        ys.append(ty)
+        hosts.append(_HostSide(m.model, m.likelihood, tx.shape[1]))
+    d = xs[0].shape[1]
+    if any(x.shape[1] != d for x in xs) or any(h.name != hosts[0].name for h in hosts):
+        raise ValueError("fit_many needs sites of one model family and one input dimension")
+    sizes = [x.shape[0] for x in xs]
+    n = max(sizes)
+    plan = GPPlan(hosts[0].name, n, d, dtype=dtype, device=device, lookahead=1 if B > 1 else 2, batch=B)
+    if B > 1:
+        plan.set_site_sizes(sizes)
+
+    def slots(ts):
+        out = torch.zeros((B, n) + tuple(ts[0].shape[1:]), dtype=dtype)
+        for b, t in enumerate(ts):
+            out[b, : t.shape[0]] = t
+        return out.to(device).contiguous()
+
+    X, Y = slots(xs), slots(ys)
+    noise = slots([m.likelihood.noise.reshape(-1).to(dtype) for m in models])
+    nvec = torch.tensor(sizes, dtype=torch.float64)
+    plan.set_inputs(X if B > 1 else X[0].contiguous())
+
+    # stacked state of the per-site host modules: every parameter, and the buffers that have one shape across the
+    # sites (constraint bounds, prior hyperparameters); site-shaped buffers (the fixed noise) stay the module's own
+    params = {k: torch.stack([dict(h.named_parameters())[k].detach() for h in hosts]).clone().requires_grad_(True)
+              for k, _ in hosts[0].named_parameters()}
+    buffers = {}
+    for k, b0 in hosts[0].named_buffers():
+        bs = [dict(h.named_buffers())[k] for h in hosts]
+        if all(b.shape == b0.shape for b in bs):
+            buffers[k] = torch.stack(bs)
+    host0 = hosts[0]
+
+    def one_site(p, b):
+        return functional_call(host0, (p, b), ())
+
+    host_all = vmap(one_site)
+
+    # ---- per-site optimiser state (torch.optim.Adam + ReduceLROnPlateau semantics, vectorised over the sites)
+    lr = torch.full((B,), float(learning_rate), dtype=torch.float64)
+    step = torch.zeros(B, dtype=torch.float64)
+    m1 = {k: torch.zeros_like(v) for k, v in params.items()}
+    m2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    beta1, beta2, eps, wd = 0.9, 0.999, 1e-8, 1e-4
+    best = torch.full((B,), float("inf"), dtype=torch.float64)
+    num_bad = torch.zeros(B, dtype=torch.float64)
+    cooldown = torch.zeros(B, dtype=torch.float64)
+    sched_patience, factor, threshold, cool, min_lr = max(20, patience // 2), 0.7, 1e-4, 10, 1e-6
+    nan_run = torch.zeros(B, dtype=torch.float64)
+    last_obj = torch.full((B,), float("nan"), dtype=torch.float64)
+
+    def per_site(t, v):  # broadcast a (B,) vector against a stacked parameter
+        return v.reshape((B,) + (1,) * (t.dim() - 1))
+
+    for it in range(iterations):
+        for v in params.values():
+            v.grad = None
+        theta, lp, c = host_all(params, buffers)
+        r = (Y - c.to(device, dtype)[:, None]).contiguous()
+        nll = _BatchedNLL.apply(plan, theta, r, noise) if B > 1 else _single(plan, theta, r, noise)
+        obj = (nll - lp) / nvec
+        ok = torch.isfinite(obj.detach())
+        nan_run = torch.where(ok, torch.zeros_like(nan_run), nan_run + 1)
+        if bool((nan_run > 10).any()):
+            raise RuntimeError(f"site {int(torch.argmax(nan_run))}: more than 10 consecutive NaN/Inf objectives "
+                               f"at iteration {it + 1}")
+        torch.where(ok, obj, torch.zeros_like(obj)).sum().backward()
+        grads = {k: torch.nan_to_num(v.grad, nan=0.0, posinf=0.0, neginf=0.0) for k, v in params.items()}
+        # clip_grad_norm_(max_norm=1.0) per site
+        sq = sum((g.reshape(B, -1) ** 2).sum(dim=1) for g in grads.values())
+        coef = torch.clamp(1.0 / (torch.sqrt(sq) + 1e-6), max=1.0)
+        okf = ok.to(torch.float64)
+        step = step + okf
+        bc1 = 1.0 - beta1 ** step
+        bc2 = 1.0 - beta2 ** step
+        with torch.no_grad():
+            for k, p in params.items():
+                g = grads[k] * per_site(p, coef) + wd * p
+                mk = per_site(p, okf)
+                m1[k] = torch.where(mk > 0, beta1 * m1[k] + (1 - beta1) * g, m1[k])
+                m2[k] = torch.where(mk > 0, beta2 * m2[k] + (1 - beta2) * g * g, m2[k])
+                denom = torch.sqrt(m2[k]) / per_site(p, torch.sqrt(torch.clamp(bc2, min=1e-300))) + eps
+                upd = per_site(p, lr / torch.clamp(bc1, min=1e-300)) * m1[k] / denom
+                p -= torch.where(mk > 0, upd, torch.zeros_like(upd))
+        last_obj = torch.where(ok, obj.detach(), last_obj)
+        if scheduler:  # ReduceLROnPlateau.step(obj) for the sites that stepped
+            cur = obj.detach()
+            better = ok & (cur < best * (1.0 - threshold))
+            best = torch.where(better, cur, best)
+            num_bad = torch.where(ok, torch.where(better, torch.zeros_like(num_bad), num_bad + 1), num_bad)
+            in_cool = ok & (cooldown > 0)
+            cooldown = torch.where(in_cool, cooldown - 1, cooldown)
+            num_bad = torch.where(in_cool, torch.zeros_like(num_bad), num_bad)
+            reduce = ok & (num_bad > sched_patience)
+            new_lr = torch.clamp(lr * factor, min=min_lr)
+            lr = torch.where(reduce & (lr - new_lr > 1e-8), new_lr, lr)
+            cooldown = torch.where(reduce, torch.full_like(cooldown, float(cool)), cooldown)
+            num_bad = torch.where(reduce, torch.zeros_like(num_bad), num_bad)
+        if progress and (it + 1) % 10 == 0:
+            print(f"iteration {it + 1}: mean objective {float(last_obj.nanmean()):.4f}", flush=True)
+
+    # ---- hand the fitted parameters back to the per-site models
+    with torch.no_grad():
+        for b, (m, h) in enumerate(zip(models, hosts)):
+            own = dict(h.named_parameters())
+            for k, v in params.items():
+                own[k].copy_(v[b])
+            m._current_iteration = iterations - 1
+            m._setup_device(xs[b], ys[b])
+            m.model.eval()
+            m.likelihood.eval()
+            m.is_fitted = True
+    return last_obj
+
+
+def _single(plan, theta, r, noise):
+    """B = 1: the unbatched plan takes unbatched arrays."""
+    from .gp.mll import exact_gp_nll
+
+    return exact_gp_nll(plan, theta[0], r[0].contiguous(), noise[0].contiguous()).reshape(1)
+
+
+__all__ = ["fit_many"]

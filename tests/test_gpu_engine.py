@@ -148,3 +148,29 @@ def test_fit_sites_two_plans_match_sequential(gpu_device):
         assert (rag[i] - solo[0]).abs().max() <= 1e-9 * solo[0].abs().max()
     val, g, _, _ = orc.nll_data_and_grads("loadest", data[3][0].cpu(), data[3][1].cpu(), noise.cpu(), torch.tensor(theta, dtype=torch.float64))
     assert abs(two[3, 0].item() - val.item()) / abs(val.item()) < 1e-10
+
+
+def test_fit_many_follows_the_single_site_trajectories(gpu_device):
+    """``fit_many`` (one batched plan, vectorised host algebra, per-site Adam / clipping / plateau schedule) must land
+    where ``model.fit`` lands for each site on its own -- sites of different length, scheduler on."""
+    from discontinuum_amd.loadest_gp import LoadestGP
+    from discontinuum_amd.multisite_fit import fit_many
+
+    sizes, iters = [90, 64, 130, 75], 40
+    data = [loadest_dataset(k, seed=300 + i) for i, k in enumerate(sizes)]
+    solo = []
+    for cov, tgt in data:
+        m = LoadestGP()
+        m.fit(cov, tgt, iterations=iters)
+        solo.append(m)
+    many = [LoadestGP() for _ in sizes]
+    final = fit_many(many, data, iterations=iters)
+    assert final.shape == (len(sizes),) and bool(torch.isfinite(final).all())
+    for a, b, (cov, _tgt) in zip(solo, many, data):
+        assert b.is_fitted
+        pa = torch.cat([p.detach().reshape(-1) for p in a.model.parameters()])
+        pb = torch.cat([p.detach().reshape(-1) for p in b.model.parameters()])
+        assert (pa - pb).abs().max() < 1e-6, (pa - pb).abs().max()
+        ta, sa = a.predict(cov)
+        tb, sb = b.predict(cov)
+        assert np.allclose(ta.values, tb.values, rtol=1e-6) and np.allclose(sa.values, sb.values, rtol=1e-6)
