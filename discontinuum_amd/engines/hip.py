@@ -105,225 +105,212 @@ class MarginalHIP(BaseModel):
     def _param_key(self):
         return tuple(float(v) for p in self.model.parameters() for v in p.detach().reshape(-1).tolist())
 
+    # ------------------------------------------------------------------ data -> host model -> device
+    def _attach(self, covariates, target, target_unc, refit_data=True):
+        """Fit the data manager (unless the caller keeps the current one) and return the model-space training tensors
+        (x, y, y_unc or None) in ``self.dtype``."""
+        if refit_data:
+            self.dm.fit(target=target, covariates=covariates, target_unc=target_unc)
+        self.X, self.y = self.dm.X, self.dm.y
+        x = torch.tensor(self.X, dtype=self.dtype)
+        y = torch.tensor(self.y, dtype=self.dtype)
+        unc = None
+        if target_unc is not None:
+            self.y_unc = self.dm.y_unc
+            unc = torch.tensor(self.y_unc, dtype=self.dtype)
+        return x, y, unc
+
+    def _fresh_model(self, x, y, unc):
+        """``build_model`` with the reference's calling convention: the uncertainty is only passed when there is one.
+        (The hook also sets ``self.likelihood``.)"""
+        self.model = self.build_model(x, y) if unc is None else self.build_model(x, y, unc)
+
     # ------------------------------------------------------------------ checkpointing
-    @classmethod
-    def load(cls, f, covariates, target, target_unc=None):
-        """Load a checkpoint written by ``save()`` and prepare for prediction / resumed fitting
-        (engines/gpytorch.py:47-105)."""
-        ckpt = torch.load(f, map_location="cpu", weights_only=False)
-        model = cls()
-        model.dm.fit(target=target, covariates=covariates, target_unc=target_unc)
-        model.X, model.y = model.dm.X, model.dm.y
-        train_x = torch.tensor(model.X, dtype=model.dtype)
-        train_y = torch.tensor(model.y, dtype=model.dtype)
-        if target_unc is None:
-            model.model = model.build_model(train_x, train_y)
-        else:
-            model.y_unc = model.dm.y_unc
-            model.model = model.build_model(train_x, train_y, torch.tensor(model.y_unc, dtype=model.dtype))
-        model.model.load_state_dict(ckpt["model_state_dict"])
-        if ckpt.get("likelihood_state_dict") is not None:
-            model.likelihood.load_state_dict(ckpt["likelihood_state_dict"])
-        model._resume_info = {k: ckpt.get(k) for k in (
-            "optimizer_state_dict", "optimizer_name", "optimizer_lr", "scheduler_state_dict", "scheduler_name")}
-        model._resume_info["current_iteration"] = ckpt.get("current_iteration", 0)
-        model._current_iteration = ckpt.get("current_iteration", 0)
-        model._setup_device(train_x, train_y)
-        model.is_fitted = True
-        return model
+    # Dictionary layout of the reference's checkpoints (engines/gpytorch.py:107-160) so that files written by either
+    # engine load in the other: state dicts of model / likelihood / optimiser / scheduler plus bookkeeping.
+    _OPTIMIZER_KEYS = ("optimizer_state_dict", "optimizer_name", "optimizer_lr", "scheduler_state_dict", "scheduler_name")
 
     def save(self, f, optimizer_obj=None, scheduler=None, extra=None) -> None:
-        """Weights + optimizer/scheduler state, same dictionary keys as engines/gpytorch.py:147-159."""
-        if optimizer_obj is None:
-            optimizer_obj = getattr(self, "_last_optimizer", None)
-        if scheduler is None:
-            scheduler = getattr(self, "_last_scheduler", None)
-        if not hasattr(self, "model"):
-            raise RuntimeError("No model to save. Call fit() first.")
-        if not hasattr(self, "likelihood"):
-            raise RuntimeError("No likelihood to save. Call fit() first.")
-        opt_name = lr_val = None
-        if optimizer_obj is not None:
-            opt_name = _get_optimizer_name(optimizer_obj)
-            try:
-                lr_val = optimizer_obj.param_groups[0].get("lr", None)
-            except Exception:  # noqa: BLE001
-                lr_val = None
-        torch.save({
-            "model_class": f"{self.__class__.__module__}.{self.__class__.__name__}",
+        for attr in ("model", "likelihood"):
+            if not hasattr(self, attr):
+                raise RuntimeError(f"No {attr} to save. Call fit() first.")
+        opt = optimizer_obj if optimizer_obj is not None else getattr(self, "_last_optimizer", None)
+        sch = scheduler if scheduler is not None else getattr(self, "_last_scheduler", None)
+        record = {
+            "model_class": f"{type(self).__module__}.{type(self).__name__}",
+            "model_config": getattr(self, "model_config", None),
+            "current_iteration": getattr(self, "_current_iteration", 0),
+            "extra": extra or {},
             "model_state_dict": self.model.state_dict(),
             "likelihood_state_dict": self.likelihood.state_dict(),
-            "optimizer_state_dict": optimizer_obj.state_dict() if optimizer_obj is not None else None,
-            "optimizer_name": opt_name,
-            "optimizer_lr": lr_val,
-            "scheduler_state_dict": scheduler.state_dict() if scheduler is not None else None,
-            "scheduler_name": scheduler.__class__.__name__ if scheduler is not None else None,
-            "current_iteration": getattr(self, "_current_iteration", 0),
-            "model_config": getattr(self, "model_config", None),
-            "extra": extra or {},
-        }, f)
+            "optimizer_state_dict": None, "optimizer_name": None, "optimizer_lr": None,
+            "scheduler_state_dict": None, "scheduler_name": None,
+        }
+        if opt is not None:
+            groups = getattr(opt, "param_groups", None) or [{}]
+            record.update(optimizer_state_dict=opt.state_dict(), optimizer_name=_get_optimizer_name(opt),
+                          optimizer_lr=groups[0].get("lr"))
+        if sch is not None:
+            record.update(scheduler_state_dict=sch.state_dict(), scheduler_name=type(sch).__name__)
+        torch.save(record, f)
+
+    @classmethod
+    def load(cls, f, covariates, target, target_unc=None):
+        """A model restored from ``save()`` output and re-attached to its data: ready to predict, or to continue
+        training with ``fit(..., resume=True)`` (engines/gpytorch.py:47-105)."""
+        record = torch.load(f, map_location="cpu", weights_only=False)
+        self = cls()
+        x, y, unc = self._attach(covariates, target, target_unc)
+        self._fresh_model(x, y, unc)
+        self.model.load_state_dict(record["model_state_dict"])
+        if record.get("likelihood_state_dict") is not None:
+            self.likelihood.load_state_dict(record["likelihood_state_dict"])
+        self._current_iteration = record.get("current_iteration", 0)
+        self._resume_info = {key: record.get(key) for key in cls._OPTIMIZER_KEYS}
+        self._resume_info["current_iteration"] = self._current_iteration
+        self._setup_device(x, y)
+        self.is_fitted = True
+        return self
 
     # ------------------------------------------------------------------ fit
+    @staticmethod
+    def _new_optimizer(params, name, lr):
+        """The reference's two optimisers with its hyperparameters (engines/gpytorch.py:268-288)."""
+        decay = {"adam": (torch.optim.Adam, 1e-4), "adamw": (torch.optim.AdamW, 1e-2)}
+        if name not in decay:
+            raise ValueError(f"Unsupported optimizer: {name!r}. Supported optimizers are 'adam' and 'adamw'.")
+        cls, weight_decay = decay[name]
+        # foreach: the same update rule as one multi-tensor call per step
+        return cls(params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay, foreach=True)
+
+    @staticmethod
+    def _restore(obj, state):
+        """Best-effort ``load_state_dict`` (a checkpoint from another optimiser layout must not stop a fit)."""
+        if obj is not None and state is not None:
+            try:
+                obj.load_state_dict(state)
+            except Exception:  # noqa: BLE001, S110
+                pass
+
     def fit(self, covariates, target, target_unc=None, iterations: int = 100, optimizer: str | None = None,
             learning_rate: float | None = None, early_stopping: bool = False, patience: int = 60,
             scheduler: bool = True, resume: bool = False, penalty_callback=None, penalty_weight: float = 0.0):
-        """Fit the model to data; parameters as ``MarginalGPyTorch.fit`` (engines/gpytorch.py:162-212)."""
-        has_model = (getattr(self, "model", None) is not None and getattr(self, "likelihood", None) is not None
-                     and self.is_fitted)
-        from_checkpoint = self._resume_info is not None and has_model
-        from_interruption = resume and has_model and not from_checkpoint
-        if not from_interruption:
-            self.dm.fit(target=target, covariates=covariates, target_unc=target_unc)
-        self.X, self.y = self.dm.X, self.dm.y
-        train_x = torch.tensor(self.X, dtype=self.dtype)
-        train_y = torch.tensor(self.y, dtype=self.dtype)
-        can_restore = from_checkpoint or from_interruption
-
-        def fresh_build():
-            if target_unc is None:
-                self.model = self.build_model(train_x, train_y)  # also sets self.likelihood
-            else:
-                self.y_unc = self.dm.y_unc
-                self.model = self.build_model(train_x, train_y, torch.tensor(self.y_unc, dtype=self.dtype))
-
-        if not can_restore:
-            fresh_build()
-        elif from_checkpoint:
+        """Train the hyperparameters; arguments and behaviour as ``MarginalGPyTorch.fit``
+        (engines/gpytorch.py:162-458): Adam (default lr 0.05) or AdamW, gradient clipping to norm 1, optional
+        ReduceLROnPlateau, NaN iterations skipped (more than ten in a row raise), optional early stopping, resume from a
+        checkpoint (``load``) or from an interrupted call (``resume=True``), optional penalty term."""
+        trained = bool(getattr(self, "model", None) is not None and getattr(self, "likelihood", None) is not None
+                       and self.is_fitted)
+        from_checkpoint = trained and self._resume_info is not None
+        from_interruption = trained and resume and not from_checkpoint
+        x, y, unc = self._attach(covariates, target, target_unc, refit_data=not from_interruption)
+        restore = from_checkpoint or from_interruption
+        if from_checkpoint:
             try:
-                self.model.set_train_data(inputs=train_x, targets=train_y, strict=False)
+                self.model.set_train_data(inputs=x, targets=y, strict=False)
             except Exception:  # noqa: BLE001
-                fresh_build()
-                can_restore = False
-        self._setup_device(train_x, train_y)
+                restore = False
+        if not restore:
+            self._fresh_model(x, y, unc)
+        self._setup_device(x, y)
         self.model.train()
         self.likelihood.train()
 
-        resume_info = self._resume_info or {}
+        # what a previous run left behind: a checkpoint's record, or the live optimiser of an interrupted call
+        previous = dict(self._resume_info or {})
         if from_interruption and self._last_optimizer is not None:
-            resume_info = {
-                "optimizer_name": _get_optimizer_name(self._last_optimizer),
-                "optimizer_lr": self._last_optimizer.param_groups[0]["lr"] if self._last_optimizer.param_groups else None,
-                "optimizer_state_dict": self._last_optimizer.state_dict(),
-                "scheduler_state_dict": self._last_scheduler.state_dict() if self._last_scheduler else None,
-            }
-        saved_name, saved_lr = resume_info.get("optimizer_name"), resume_info.get("optimizer_lr")
-        opt_choice = optimizer if optimizer is not None else (saved_name or "adam")
-        lr_choice = learning_rate if learning_rate is not None else (saved_lr or 0.05)
+            groups = self._last_optimizer.param_groups
+            previous = {"optimizer_name": _get_optimizer_name(self._last_optimizer),
+                        "optimizer_lr": groups[0]["lr"] if groups else None,
+                        "optimizer_state_dict": self._last_optimizer.state_dict(),
+                        "scheduler_state_dict": self._last_scheduler.state_dict() if self._last_scheduler else None}
+        # a saved optimiser kind outranks the argument, as in the reference (engines/gpytorch.py:268-288)
+        saved = (previous.get("optimizer_name") or "").lower()
+        asked = optimizer if optimizer is not None else (saved or "adam")
+        name = next((kind for kind in ("adamw", "adam") if kind in (asked, saved)), asked)
+        lr = learning_rate if learning_rate is not None else (previous.get("optimizer_lr") or 0.05)
         params = list(self.model.parameters())
-        if opt_choice == "adamw" or (saved_name and saved_name.lower() == "adamw"):
-            optimizer_obj = torch.optim.AdamW(params, lr=lr_choice, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                                              foreach=True)
-        elif opt_choice == "adam" or (saved_name and saved_name.lower() == "adam"):
-            optimizer_obj = torch.optim.Adam(params, lr=lr_choice, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4,
-                                             foreach=True)  # same update rule, one multi-tensor call per step
-        else:
-            raise ValueError(f"Unsupported optimizer: {opt_choice!r}. Supported optimizers are 'adam' and 'adamw'.")
-        if can_restore and resume_info.get("optimizer_state_dict") is not None:
-            try:
-                optimizer_obj.load_state_dict(resume_info["optimizer_state_dict"])
-            except Exception:  # noqa: BLE001, S110
-                pass
+        optimizer_obj = self._new_optimizer(params, name, lr)
         scheduler_obj = None
         if scheduler:
             scheduler_obj = torch.optim.lr_scheduler.ReduceLROnPlateau(
                 optimizer_obj, mode="min", factor=0.7, patience=max(20, patience // 2), threshold=1e-4,
                 threshold_mode="rel", min_lr=1e-6, cooldown=10)
-            if can_restore and resume_info.get("scheduler_state_dict") is not None:
-                try:
-                    scheduler_obj.load_state_dict(resume_info["scheduler_state_dict"])
-                except Exception:  # noqa: BLE001, S110
-                    pass
+        if restore:
+            self._restore(optimizer_obj, previous.get("optimizer_state_dict"))
+            self._restore(scheduler_obj, previous.get("scheduler_state_dict"))
 
-        mll = ExactMarginalLogLikelihood(self.likelihood, self.model)
-
-        start_iteration = self._current_iteration if (resume and hasattr(self, "_current_iteration")) else 0
-        if iterations - start_iteration <= 0:
-            print(f"Model already trained for {start_iteration} iterations (>= target {iterations}). "
-                  "No further training needed.")
+        first = self._current_iteration if (resume and hasattr(self, "_current_iteration")) else 0
+        if iterations <= first:
+            print(f"Model already trained for {first} iterations (>= target {iterations}). No further training needed.")
             return
-        pbar = tqdm.tqdm(range(iterations - start_iteration), ncols=100, desc=f"Training {start_iteration}->{iterations}")
-        best_obj, patience_counter, min_improvement = float("inf"), 0, 1e-6
-        nan_loss_counter = 0
-        i = 0
-
-        def plateau_bookkeeping(obj_item):
-            nonlocal best_obj, patience_counter
-            if obj_item < best_obj - min_improvement:
-                best_obj, patience_counter = obj_item, 0
-            else:
-                patience_counter += 1
-            if early_stopping and patience_counter >= patience:
-                print(f"\nEarly stopping triggered after {i + 1} iterations")
-                print(f"Best objective: {best_obj:.6f}")
-                return True
-            return False
-
+        mll = ExactMarginalLogLikelihood(self.likelihood, self.model)
+        bar = tqdm.tqdm(range(iterations - first), ncols=100, desc=f"Training {first}->{iterations}")
+        best, stale, bad_in_a_row, i = float("inf"), 0, 0, 0
+        use_penalty = penalty_callback is not None and penalty_weight > 0.0
         try:
-            for i in pbar:
-                self._current_iteration = start_iteration + i
+            for i in bar:
+                self._current_iteration = first + i
                 optimizer_obj.zero_grad(set_to_none=True)
-                output = self._prior()
+                spec = self._prior()
                 try:
-                    nll = -mll(output, self._train_y)
+                    objective = -mll(spec, self._train_y)
                 except Exception:
-                    nan_loss_counter += 1
-                    if nan_loss_counter > 10:
+                    bad_in_a_row += 1
+                    if bad_in_a_row > 10:
                         raise
                     continue
-                penalty_val = None
-                if penalty_callback is not None and penalty_weight > 0.0:
+                penalty = None
+                if use_penalty:
                     try:
-                        penalty_val = penalty_callback()
-                        if not torch.is_tensor(penalty_val):
-                            penalty_val = None
+                        value = penalty_callback()
+                        penalty = value if torch.is_tensor(value) else None
                     except Exception:  # noqa: BLE001
-                        penalty_val = None
-                objective = nll
-                if penalty_val is not None:
-                    objective = objective + float(penalty_weight) * penalty_val.to(nll.device, nll.dtype)
-                if torch.isnan(objective) or torch.isinf(objective):
-                    nan_loss_counter += 1
-                    if nan_loss_counter > 10:
+                        penalty = None
+                    if penalty is not None:
+                        objective = objective + float(penalty_weight) * penalty.to(objective.device, objective.dtype)
+                if not bool(torch.isfinite(objective).all()):
+                    bad_in_a_row += 1
+                    if bad_in_a_row > 10:
                         raise RuntimeError(
                             f"Encountered more than 10 consecutive NaN/Inf objectives at iteration {i + 1}")
                     continue
-                nan_loss_counter = 0
+                bad_in_a_row = 0
                 objective.backward()
                 total_norm = torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
                 # the reference scans every p.grad for NaN after clipping (engines/gpytorch.py:387-392); a clipped
                 # gradient holds a NaN exactly when the pre-clip norm is NaN or Inf (Inf * 0 = NaN), so one scalar says it
-                has_nan_grad = not math.isfinite(float(total_norm))
-                if has_nan_grad:
+                grads_broken = not math.isfinite(float(total_norm))
+                if grads_broken:
                     for p in params:
                         if p.grad is not None:
                             p.grad = torch.nan_to_num(p.grad, nan=0.0, posinf=0.0, neginf=0.0)
                 optimizer_obj.step()
-                obj_item = float(objective.item())
+                value = float(objective.item())
                 if scheduler_obj is not None:
-                    scheduler_obj.step(obj_item)
-                stop = plateau_bookkeeping(obj_item)
-                if has_nan_grad:
-                    if stop:
-                        break
-                    continue
-                suffix = f"obj={obj_item:.4f}, lr={optimizer_obj.param_groups[0]['lr']:.1e}"
-                if penalty_val is not None:
-                    try:
-                        suffix += f", pen={float(penalty_val.item()):.3e}"
-                    except Exception:  # noqa: BLE001, S110
-                        pass
-                pbar.set_postfix_str(suffix)
+                    scheduler_obj.step(value)
+                if value < best - 1e-6:
+                    best, stale = value, 0
+                else:
+                    stale += 1
+                stop = early_stopping and stale >= patience
+                if stop:
+                    print(f"\nEarly stopping triggered after {i + 1} iterations")
+                    print(f"Best objective: {best:.6f}")
+                if not grads_broken:
+                    note = f"obj={value:.4f}, lr={optimizer_obj.param_groups[0]['lr']:.1e}"
+                    if penalty is not None and bool(torch.isfinite(penalty).all()):
+                        note += f", pen={float(penalty):.3e}"
+                    bar.set_postfix_str(note)
                 if stop:
                     break
         except KeyboardInterrupt:
             print(f"\nTraining interrupted at iteration {i + 1}")
-            print(f"Best objective: {best_obj:.6f}")
+            print(f"Best objective: {best:.6f}")
         finally:
             self.is_fitted = True
-        self._last_optimizer = optimizer_obj
-        self._last_scheduler = scheduler_obj
+        self._last_optimizer, self._last_scheduler = optimizer_obj, scheduler_obj
         self._factor_key = None
-        return
 
     # ------------------------------------------------------------------ prediction
     def _ensure_factor(self):

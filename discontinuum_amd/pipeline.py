@@ -157,59 +157,61 @@ class Pipeline:
         return X
 
 
-class LogStandardPipeline(Pipeline):
+def _recipe(doc, *steps, **methods):
+    """A named pipeline class from its recipe: ``(step name, step class, constructor kwargs)`` triples.  Every instance
+    builds fresh step objects, so fitted state is never shared between pipelines."""
+
     def __init__(self):
-        super().__init__([("metadata", MetadataManager()), ("clip", ClipTransformer(min=1e-6)),
-                          ("log", LogTransformer()), ("scaler", StandardScaler())])
+        Pipeline.__init__(self, [(name, cls(**kwargs)) for name, cls, kwargs in steps])
+
+    return type("_", (Pipeline,), {"__init__": __init__, "__doc__": doc, **methods})
 
 
-class NoOpPipeline(Pipeline):
-    def __init__(self):
-        super().__init__([("metadata", MetadataManager()), ("clip", ClipTransformer(min=0))])
+def _named(cls, name):
+    cls.__name__ = cls.__qualname__ = name
+    return cls
 
 
-class StandardPipeline(Pipeline):
-    def __init__(self):
-        super().__init__([("metadata", MetadataManager()), ("clip", ClipTransformer(min=0)),
-                          ("scaler", StandardScaler())])
+_META = ("metadata", MetadataManager, {})
+_NONNEG = ("clip", ClipTransformer, {"min": 0})
 
-
-class UnitPipeline(Pipeline):
-    def __init__(self):
-        super().__init__([("metadata", MetadataManager()), ("clip", ClipTransformer(min=0)),
-                          ("scaler", UnitScaler(zero_value=1))])
-
-
-class TimePipeline(Pipeline):
-    def __init__(self):
-        super().__init__([("metadata", MetadataManager()), ("decimal_year", TimeTransformer()),
-                          ("scaler", StandardScaler(with_std=False))])
+# The reference's pipelines, step for step (src/discontinuum/pipeline.py:242-403): name -> recipe.
+LogStandardPipeline = _named(_recipe(
+    "Positive, log-normally distributed data: clip at 1e-6, log, standardise.",
+    _META, ("clip", ClipTransformer, {"min": 1e-6}), ("log", LogTransformer, {}), ("scaler", StandardScaler, {})),
+    "LogStandardPipeline")
+NoOpPipeline = _named(_recipe("Non-negative data passed through unchanged.", _META, _NONNEG), "NoOpPipeline")
+StandardPipeline = _named(_recipe(
+    "Non-negative, roughly normal data: standardise.", _META, _NONNEG, ("scaler", StandardScaler, {})),
+    "StandardPipeline")
+UnitPipeline = _named(_recipe(
+    "Non-negative data rescaled to [1, 2] (minimum -> 1, maximum -> 2).",
+    _META, _NONNEG, ("scaler", UnitScaler, {"zero_value": 1})), "UnitPipeline")
+TimePipeline = _named(_recipe(
+    "Timestamps -> centred decimal years (mean removed, scale kept).",
+    _META, ("decimal_year", TimeTransformer, {}), ("scaler", StandardScaler, {"with_std": False})), "TimePipeline")
 
 
 def _zscore(ci):
     return norm.ppf(1 - (1 - ci) / 2)
 
 
-class StandardErrorPipeline(Pipeline):
-    """inverse_transform turns a model-space variance into a standard error."""
-
-    def __init__(self):
-        super().__init__([("metadata", MetadataManager()), ("scaler", StandardScaler(with_mean=False)),
-                          ("square", SquareTransformer()), ("clip", ClipTransformer(min=0))])
-
-    def ci(self, mean, se, ci=0.95):
-        half = se * _zscore(ci)
-        return mean - half, mean + half
+def _additive_ci(self, mean, se, ci=0.95):
+    half = se * _zscore(ci)
+    return mean - half, mean + half
 
 
-class LogErrorPipeline(Pipeline):
-    """inverse_transform turns a log-space variance into a geometric standard error."""
+def _multiplicative_ci(self, mean, se, ci=0.95):
+    factor = se ** _zscore(ci)
+    return mean / factor, mean * factor
 
-    def __init__(self):
-        super().__init__([("metadata", MetadataManager()), ("log", LogTransformer()),
-                          ("scaler", StandardScaler(with_mean=False)), ("square", SquareTransformer()),
-                          ("clip", ClipTransformer(min=1e-6))])
 
-    def ci(self, mean, se, ci=0.95):
-        factor = se ** _zscore(ci)
-        return mean / factor, mean * factor
+# error pipelines: ``inverse_transform`` takes a model-space VARIANCE to a standard error in data space
+StandardErrorPipeline = _named(_recipe(
+    "Variance of standardised data -> standard error; ``ci`` is mean -/+ z se.",
+    _META, ("scaler", StandardScaler, {"with_mean": False}), ("square", SquareTransformer, {}), _NONNEG,
+    ci=_additive_ci), "StandardErrorPipeline")
+LogErrorPipeline = _named(_recipe(
+    "Variance of log-standardised data -> geometric standard error; ``ci`` is mean / se^z .. mean * se^z.",
+    _META, ("log", LogTransformer, {}), ("scaler", StandardScaler, {"with_mean": False}), ("square", SquareTransformer, {}),
+    ("clip", ClipTransformer, {"min": 1e-6}), ci=_multiplicative_ci), "LogErrorPipeline")
