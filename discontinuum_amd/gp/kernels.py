@@ -1,9 +1,9 @@
 """Declarative kernel tree (the "kernel-spec IR") mirroring the gpytorch classes the reference composes.
 
-``build_model`` in the model packages reads exactly like the reference's
+The model packages compose these classes into the reference's covariance functions
 (``src/loadest_gp/models/gpytorch.py:61-128``, ``src/rating_gp/models/gpytorch.py:205-372``,
 ``src/rating_gp/models/kernels.py:242-382``): same class names, constructor arguments, ``+`` / ``*``
-composition, raw-parameter names and shapes, constraints and priors.  The tree holds NO arithmetic:
+composition, raw-parameter names and shapes, constraints and priors -- hence the same ``state_dict`` keys.  The tree holds NO arithmetic:
 ``discontinuum_amd.gp.lowering`` maps it onto one of the fused HIP evaluators
 (``csrc/dgp_models.h``) and fails loudly for any structure the hardware path does not implement.
 """
