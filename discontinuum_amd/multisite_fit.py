@@ -15,8 +15,9 @@ step applied per site:
   more than 10 in a row raise                                            (``:352-379``)
 
 so each site follows the trajectory ``model.fit`` would give it (tests/test_gpu_engine.py compares them).  Afterwards
-every model holds its fitted parameters and is ready for ``predict``.  Scope: models whose host side is plain
-elementwise torch (loadest-gp); rating-gp's mean clamps parameters in place per call and stays on ``model.fit``.
+every model holds its fitted parameters and is ready for ``predict``.  Both model families are covered: loadest-gp
+(constant mean, fixed noise) and rating-gp (power-law mean whose parameters the reference clamps in place on every
+forward -- done here once per iteration on the stacked parameters -- and a learned homoskedastic noise term).
 Not supported here: early stopping, resume, penalty callbacks, AdamW.
 """
 from __future__ import annotations
@@ -47,7 +48,13 @@ class _HostSide(nn.Module):
         lp = torch.zeros((), dtype=torch.float64)
         for prior, closure, mod in self._priors:
             lp = lp + prior.log_prob(closure(mod)).sum()
-        return self._theta(), lp, self.model.mean_module.constant.reshape(())
+        if self.name == "rating":  # power law a, b, c and the learned noise term
+            pw = self.model.powerlaw
+            extras = torch.cat([pw.a.reshape(1), pw.b.reshape(1), pw.c.reshape(1),
+                                self.model.likelihood.second_noise.reshape(1)])
+        else:
+            extras = self.model.mean_module.constant.reshape(1)
+        return self._theta(), lp, extras
 
 
 class _BatchedNLL(torch.autograd.Function):
@@ -55,39 +62,40 @@ class _BatchedNLL(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, plan, theta, r, noise):
-        out, dr, _dnoise = plan.fit_step(theta, r, noise)
+        out, dr, dnoise = plan.fit_step(theta, r, noise)
         host = out.to("cpu", torch.float64)
         ok = (host[:, _lib.OUT_INFO] == 0) & torch.isfinite(host[:, _lib.OUT_NLL])
         dtheta = torch.nan_to_num(host[:, _lib.OUT_DTHETA:_lib.OUT_DTHETA + plan.ntheta], nan=0.0, posinf=0.0, neginf=0.0)
         dtheta = dtheta * ok[:, None]
-        dr = torch.nan_to_num(dr, nan=0.0, posinf=0.0, neginf=0.0) * ok.to(dr.device)[:, None]
-        ctx.save_for_backward(dtheta, dr)
+        okd = ok.to(dr.device)[:, None]
+        dr = torch.nan_to_num(dr, nan=0.0, posinf=0.0, neginf=0.0) * okd
+        dnoise = torch.nan_to_num(dnoise, nan=0.0, posinf=0.0, neginf=0.0) * okd
+        ctx.save_for_backward(dtheta, dr, dnoise)
         ctx.theta_dtype = theta.dtype
         return torch.where(ok, host[:, _lib.OUT_NLL], torch.full_like(host[:, 0], float("nan")))
 
     @staticmethod
     def backward(ctx, g):
-        dtheta, dr = ctx.saved_tensors
+        dtheta, dr, dnoise = ctx.saved_tensors
         g = torch.nan_to_num(g, nan=0.0)
-        return None, (dtheta * g[:, None]).to(ctx.theta_dtype), dr * g.to(dr.device, dr.dtype)[:, None], None
+        gd = g.to(dr.device, dr.dtype)[:, None]
+        return None, (dtheta * g[:, None]).to(ctx.theta_dtype), dr * gd, dnoise * gd
 
 
 def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.05, patience: int = 60,
              scheduler: bool = True, progress: bool = False):
-    """Fit ``models[i]`` to ``datasets[i] = (covariates, target)`` for all i at once.  Returns the per-site final
-    objectives (a float64 tensor); the models are updated in place (``is_fitted``, parameters, device state)."""
+    """Fit ``models[i]`` to ``datasets[i] = (covariates, target[, target_unc])`` for all i at once.  Returns the
+    per-site final objectives (a float64 tensor); the models are updated in place (``is_fitted``, parameters, device
+    state)."""
     if len(models) != len(datasets) or not models:
         raise ValueError("fit_many needs one (covariates, target) pair per model")
     B = len(models)
     dtype, device = models[0].dtype, torch.device(models[0].device)
     xs, ys, hosts = [], [], []
-    for m, (cov, tgt) in zip(models, datasets):
-        m.dm.fit(target=tgt, covariates=cov, target_unc=None)
-        m.X, m.y = m.dm.X, m.dm.y
-        tx, ty = torch.tensor(m.X, dtype=dtype), torch.tensor(m.y, dtype=dtype)
-        m.model = m.build_model(tx, ty)
-        if hasattr(m.model, "prepare_eval") or not hasattr(m.model.mean_module, "constant"):
-            raise NotImplementedError("fit_many supports models with a constant mean (loadest-gp); use model.fit")
+    for m, record in zip(models, datasets):
+        cov, tgt, unc = (tuple(record) + (None,))[:3]
+        tx, ty, tu = m._attach(cov, tgt, unc)
+        m._fresh_model(tx, ty, tu)
         m.model.train()
         m.likelihood.train()
         xs.append(tx)
@@ -109,8 +117,21 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
         return out.to(device).contiguous()
 
     X, Y = slots(xs), slots(ys)
-    noise = slots([m.likelihood.noise.reshape(-1).to(dtype) for m in models])
+    fixed_noise = slots([m.likelihood.noise.reshape(-1).to(dtype) for m in models])
     nvec = torch.tensor(sizes, dtype=torch.float64)
+    family = hosts[0].name
+    valid = (torch.arange(n)[None, :] < torch.tensor(sizes)[:, None]).to(device)  # (B, n): real observations
+    if family == "rating":
+        stage = torch.where(valid, X[:, :, 1], torch.full_like(X[:, :, 1], 2.0))  # finite filler in the unused slots
+        stage_floor = torch.stack([x[:, 1].min() for x in xs]).to(torch.float64) - 1e-6
+
+    def mean_and_noise(extras):
+        """Prior mean and noise diagonal of every site in its slots (device, differentiable w.r.t. ``extras``)."""
+        e = extras.to(device, dtype)
+        if family == "rating":
+            mean = e[:, 0:1] + e[:, 1:2] * torch.log(stage - e[:, 2:3])
+            return mean, fixed_noise + e[:, 3:4]
+        return e[:, 0:1].expand(B, n), fixed_noise
     plan.set_inputs(X if B > 1 else X[0].contiguous())
 
     # stacked state of the per-site host modules: every parameter, and the buffers that have one shape across the
@@ -125,7 +146,9 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     host0 = hosts[0]
 
     def one_site(p, b):
-        return functional_call(host0, (p, b), ())
+        # tie_weights=False: the rating gate module sits at two places in the tree; swapping each registered name once
+        # (what named_parameters lists) is what restores cleanly
+        return functional_call(host0, (p, b), (), tie_weights=False)
 
     host_all = vmap(one_site)
 
@@ -148,8 +171,15 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     for it in range(iterations):
         for v in params.values():
             v.grad = None
-        theta, lp, c = host_all(params, buffers)
-        r = (Y - c.to(device, dtype)[:, None]).contiguous()
+        if family == "rating":  # the reference's in-forward clamps (rating_gp/models/gpytorch.py:39, 259)
+            with torch.no_grad():
+                params["model.powerlaw.b"].clamp_(1.2, 2.5)
+                pc = params["model.powerlaw.c"]
+                pc.copy_(torch.minimum(pc, stage_floor.reshape(pc.shape)))
+        theta, lp, extras = host_all(params, buffers)
+        mean, noise = mean_and_noise(extras)
+        r = (Y - mean).contiguous()
+        noise = noise.contiguous()
         nll = _BatchedNLL.apply(plan, theta, r, noise) if B > 1 else _single(plan, theta, r, noise)
         obj = (nll - lp) / nvec
         ok = torch.isfinite(obj.detach())

@@ -174,3 +174,41 @@ def test_fit_many_follows_the_single_site_trajectories(gpu_device):
         ta, sa = a.predict(cov)
         tb, sb = b.predict(cov)
         assert np.allclose(ta.values, tb.values, rtol=1e-6) and np.allclose(sa.values, sb.values, rtol=1e-6)
+
+
+def test_fit_many_rating_follows_the_single_site_trajectories(gpu_device):
+    """rating-gp through ``fit_many``: power-law mean with its per-iteration clamps, learned extra noise, per-site gate
+    interval and measurement variances -- against ``model.fit`` per site (identical initial draws per site)."""
+    from discontinuum_amd.multisite_fit import fit_many
+    from discontinuum_amd.rating_gp import RatingGP
+
+    class Seeded(RatingGP):
+        seed = 0
+
+        def build_model(self, *args):
+            torch.manual_seed(self.seed)
+            return super().build_model(*args)
+
+    sizes, iters = [70, 48, 96], 30
+    data = [rating_dataset(k, seed=500 + i) for i, k in enumerate(sizes)]
+
+    def new(i):
+        m = Seeded()
+        m.seed = 900 + i
+        return m
+
+    solo = []
+    for i, (cov, tgt, unc) in enumerate(data):
+        m = new(i)
+        m.fit(cov, tgt, target_unc=unc, iterations=iters)
+        solo.append(m)
+    many = [new(i) for i in range(len(sizes))]
+    final = fit_many(many, data, iterations=iters)
+    assert bool(torch.isfinite(final).all())
+    for a, b, (cov, _tgt, _unc) in zip(solo, many, data):
+        pa = torch.cat([p.detach().reshape(-1) for p in a.model.parameters()])
+        pb = torch.cat([p.detach().reshape(-1) for p in b.model.parameters()])
+        assert (pa - pb).abs().max() < 1e-6, (pa - pb).abs().max()
+        ta, _ = a.predict(cov)
+        tb, _ = b.predict(cov)
+        assert np.allclose(ta.values, tb.values, rtol=1e-6)
