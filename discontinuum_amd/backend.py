@@ -149,7 +149,7 @@ class GPPlan:
             _lib.check(self.lib.dgp_factorize(self._h, th, _ptr(r), _ptr(noise), _ptr(out), _stream()), "dgp_factorize")
         return out
 
-    def predict(self, theta, Xs: torch.Tensor, chunk: int = 4096):
+    def predict(self, theta, Xs: torch.Tensor, chunk: int = 16384):
         """Latent posterior (K*^T alpha, diag(K** - K*^T K^^-1 K*)) at Xs (m, d) from the held factorisation."""
         if not (torch.is_tensor(Xs) and Xs.is_cuda and Xs.dtype == self.dtype and Xs.dim() == 2 and Xs.shape[1] == self.d):
             raise ValueError(f"Xs must be a (m, {self.d}) {self.dtype} CUDA tensor")

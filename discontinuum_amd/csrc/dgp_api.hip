@@ -473,11 +473,12 @@ static int predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, 
   T* V = (T*)w; w += align_up(e * (size_t)p->N * M);
   T* kss = (T*)w; w += align_up(e * M);
   T* mpad = (T*)w; w += align_up(e * M);
-  T* vpad = (T*)w;
+  T* vpad = (T*)w; w += align_up(e * M);
+  T* part = (T*)w;
   int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s);
   if (rc) return rc;
   if ((rc = gram_diag<T>(p->model, p->d, Xst, M, (int)m, theta, kss, s))) return rc;
-  if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, mpad, vpad, s))) return rc;
+  if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, part, mpad, vpad, s))) return rc;
   copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean, 0);
   copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(vpad, m, (T*)var, 0);
   return (int)hipGetLastError();
@@ -494,11 +495,12 @@ static int post_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t m,
   T* V = (T*)w; w += align_up(e * (size_t)p->N * M);
   T* kss = (T*)w; w += align_up(e * M);
   T* mpad = (T*)w; w += align_up(e * M);
-  T* vpad = (T*)w;
+  T* vpad = (T*)w; w += align_up(e * M);
+  T* part = (T*)w;
   int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s);
   if (rc) return rc;
   if ((rc = gram_diag<T>(p->model, p->d, Xst, M, (int)m, theta, kss, s))) return rc;
-  if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, mpad, vpad, s))) return rc;
+  if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, part, mpad, vpad, s))) return rc;
   copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean, 0);
   hipError_t he = hipMemsetAsync(vpad, 0, e * M, s);  // zero "noise" for K(Xs, Xs)
   if (he != hipSuccess) return (int)he;
@@ -637,7 +639,8 @@ int dgp_factorize(dgp_plan* p, const double* theta, const void* r, const void* n
 size_t dgp_predict_workspace_bytes(const dgp_plan* p, int64_t m) {
   if (!p || m <= 0) return 0;
   const size_t M = (size_t)round_up(m, DGP_TILE_HOST), e = p->elem;
-  return align_up(e * M * p->d) + 2 * align_up(e * (size_t)p->N * M) + 3 * align_up(e * M);
+  return align_up(e * M * p->d) + 2 * align_up(e * (size_t)p->N * M) + 3 * align_up(e * M) +
+         align_up(e * 2 * PREDICT_SPLIT * M);
 }
 
 int dgp_predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,

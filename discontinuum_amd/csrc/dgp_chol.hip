@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void predict_v_kernel(const T* __restrict__
                                                         long M, T* __restrict__ V) {
   using G = TileGemm<T, true, false>;
   __shared__ T smem[G::SMEM_ELEMS];
-  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int bi = gridDim.y - 1 - blockIdx.y, bj = blockIdx.x;  // longest row blocks first
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
   G::run(Tm + (long)bi * NB * N, N, Ks + (long)bj * NB, M, (bi + 1) * (NB / 16), smem, acc);
@@ -782,16 +782,18 @@ __global__ __launch_bounds__(256, 2) void predict_v_kernel(const T* __restrict__
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * M + c] = v; });
 }
 
+// column sums over a slab of rows: part[0][z][j] = sum_i Ks_ij alpha_i, part[1][z][j] = sum_i V_ij^2, i in slab z.
+// 64 columns x 4 row lanes per workgroup; (M/64) x PREDICT_SPLIT workgroups keep every CU reading.
 template <typename T>
-__global__ __launch_bounds__(256) void predict_reduce_kernel(const T* __restrict__ V, const T* __restrict__ Ks, long N,
-                                                             long M, const T* __restrict__ alpha,
-                                                             const T* __restrict__ kss, T* __restrict__ mean,
-                                                             T* __restrict__ var) {
+__global__ __launch_bounds__(256) void predict_partial_kernel(const T* __restrict__ V, const T* __restrict__ Ks, long N,
+                                                              long M, const T* __restrict__ alpha, T* __restrict__ part) {
   __shared__ T r1[4][64], r2[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long j = (long)blockIdx.x * 64 + tx;
+  const long rows = N / PREDICT_SPLIT;  // N % 128 == 0 and PREDICT_SPLIT divides 128
+  const long i0 = (long)blockIdx.y * rows, i1 = i0 + rows;
   T s1 = T(0), s2 = T(0);
-  for (long i = ty; i < N; i += 4) {
+  for (long i = i0 + ty; i < i1; i += 4) {
     const T v = V[i * M + j];
     s2 += v * v;
     s1 += Ks[i * M + j] * alpha[i];
@@ -800,17 +802,32 @@ __global__ __launch_bounds__(256) void predict_reduce_kernel(const T* __restrict
   r2[ty][tx] = s2;
   __syncthreads();
   if (ty == 0) {
-    mean[j] = r1[0][tx] + r1[1][tx] + r1[2][tx] + r1[3][tx];
-    var[j] = kss[j] - (r2[0][tx] + r2[1][tx] + r2[2][tx] + r2[3][tx]);
+    part[(long)blockIdx.y * M + j] = r1[0][tx] + r1[1][tx] + r1[2][tx] + r1[3][tx];
+    part[((long)PREDICT_SPLIT + blockIdx.y) * M + j] = r2[0][tx] + r2[1][tx] + r2[2][tx] + r2[3][tx];
   }
 }
 
 template <typename T>
-int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* mean, T* var,
+__global__ __launch_bounds__(256) void predict_finish_kernel(const T* __restrict__ part, long M, const T* __restrict__ kss,
+                                                             T* __restrict__ mean, T* __restrict__ var) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  T s1 = T(0), s2 = T(0);
+  for (int z = 0; z < PREDICT_SPLIT; ++z) {  // fixed order: results do not depend on scheduling
+    s1 += part[(long)z * M + j];
+    s2 += part[((long)PREDICT_SPLIT + z) * M + j];
+  }
+  mean[j] = s1;
+  var[j] = kss[j] - s2;
+}
+
+template <typename T>
+int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* part, T* mean, T* var,
                 hipStream_t s) {
   dim3 grid((unsigned)(M / NB), (unsigned)(N / NB));
   predict_v_kernel<T><<<grid, 256, 0, s>>>(Tm, N, Ks, M, V);
-  predict_reduce_kernel<T><<<(unsigned)(M / 64), 256, 0, s>>>(V, Ks, N, M, alpha, kss, mean, var);
+  predict_partial_kernel<T><<<dim3((unsigned)(M / 64), PREDICT_SPLIT), 256, 0, s>>>(V, Ks, N, M, alpha, part);
+  predict_finish_kernel<T><<<(unsigned)((M + 255) / 256), 256, 0, s>>>(part, M, kss, mean, var);
   return (int)hipGetLastError();
 }
 
@@ -848,7 +865,7 @@ int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s) {
   template int lauum<T>(const T*, long, T*, hipStream_t, Batch);                                                      \
   template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t, Batch);                           \
   template int finish<T>(const T*, const T*, long, int, T*, hipStream_t, Batch);                                      \
-  template int predict_var<T>(const T*, long, const T*, long, T*, const T*, const T*, T*, T*, hipStream_t);
+  template int predict_var<T>(const T*, long, const T*, long, T*, const T*, const T*, T*, T*, T*, hipStream_t);
 DGP_INST(double)
 DGP_INST(float)
 

@@ -75,8 +75,10 @@ int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T
           Batch bt = Batch());
 template <typename T>
 int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s, Batch bt = Batch());
+// row slabs of the prediction's column reductions (part: 2 x PREDICT_SPLIT x M elements of workspace)
+#define PREDICT_SPLIT 32
 template <typename T>
-int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* mean, T* var,
+int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* part, T* mean, T* var,
                 hipStream_t s);
 long solve_partials(long N);
 // ---- one matrix over several GPUs (block-cyclic groups of W panels; see dgp_chol.hip) ----------

@@ -300,7 +300,7 @@ class MarginalHIP(BaseModel):
                 if not grads_broken:
                     note = f"obj={value:.4f}, lr={optimizer_obj.param_groups[0]['lr']:.1e}"
                     if penalty is not None and bool(torch.isfinite(penalty).all()):
-                        note += f", pen={float(penalty):.3e}"
+                        note += f", pen={float(penalty.detach()):.3e}"
                     bar.set_postfix_str(note)
                 if stop:
                     break
