@@ -190,7 +190,10 @@ class GPPlan:
             work = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
             base = work.data_ptr() + (-work.data_ptr()) % 256
             mean = torch.empty(m, dtype=self.dtype, device=self.device)
-            fac = GPPlan(self.model, m, self.d, dtype=self.dtype, device=self.device)
+            fac = getattr(self, "_fac", None)  # the order-m plan whose potrf factors the covariance; kept between calls
+            if fac is None or fac.n != m:
+                self._fac = None
+                self._fac = fac = GPPlan(self.model, m, self.d, dtype=self.dtype, device=self.device)
             cov = fac.buffer(_lib.BUF_A)
             assert cov.shape == (M, M)
             _lib.check(

@@ -92,6 +92,12 @@ class DataManager:
     def y_t(self, y):
         return self.target_pipeline.inverse_transform(y)
 
+    def y_t_device(self, t):
+        """``y_t`` of a torch tensor: elementwise steps run where the tensor lives, then one copy to the host."""
+        device_form = getattr(self.target_pipeline, "inverse_transform_device", None)
+        out = device_form(t) if device_form is not None else None
+        return out if out is not None else self.y_t(t.cpu().numpy())
+
     def get_dim(self, dim: str) -> int:
         """Column of ``dim`` in the design matrix (coordinates first, then data variables)."""
         order = [*self.data.covariates.coords, *self.data.covariates]

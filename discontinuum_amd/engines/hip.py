@@ -387,7 +387,7 @@ class MarginalHIP(BaseModel):
             mean = mean + self.model.prior_mean(Xnew)
             z = torch.randn(cov_factor.shape[0], n, dtype=self.dtype, device=cov_factor.device)
             sim = (mean[:, None] + cov_factor @ z).T.contiguous()  # (n, m)
-        temp = self.dm.y_t(sim.reshape(-1).cpu().numpy())
+        temp = self.dm.y_t_device(sim.reshape(-1))
         data = np.asarray(temp.data).reshape(n, -1)
         return DataArray(data, coords=dict(covariates.coords, draw=np.arange(n)),
                          dims=["draw"] + list(covariates.coords), attrs=temp.attrs)

@@ -52,3 +52,23 @@ def test_data_manager_design_matrix():
     assert dm.get_dim("time") == 0 and dm.get_dim("flow") == 1
     assert np.allclose(dm.y_t(dm.y).values, tgt.values)
     assert np.allclose(dm.Xnew(cov), dm.X)
+
+
+def test_device_form_of_the_inverse_matches_numpy():
+    """``inverse_transform_device`` (what ``sample()`` uses for its 10^7 draws) against the numpy inverse, per pipeline."""
+    import torch
+
+    from discontinuum_amd.pipeline import StandardErrorPipeline, StandardPipeline
+
+    rng = np.random.default_rng(2)
+    x = DataArray(np.exp(rng.standard_normal(40)) + 0.05, dims=("time",), name="q", attrs={"units": "cfs"})
+    z = rng.standard_normal(300)
+    for cls, arg in ((LogStandardPipeline, z), (StandardPipeline, z), (UnitPipeline, 1 + rng.random(300)),
+                     (LogErrorPipeline, rng.random(300) * 0.2), (StandardErrorPipeline, rng.random(300) * 0.2)):
+        p = cls().fit(x)
+        want = p.inverse_transform(arg.copy())
+        got = p.inverse_transform_device(torch.tensor(arg.copy()))
+        assert got.name == want.name and got.attrs == want.attrs and got.dims == want.dims
+        assert np.allclose(got.values, want.values, rtol=1e-14, atol=0), cls.__name__
+    assert TimePipeline().fit(DataArray(np.array(["2020-01-01", "2021-01-01"], dtype="datetime64[ns]"), dims=("time",),
+                                        name="time")).inverse_transform_device(torch.zeros(2)) is None
