@@ -225,7 +225,7 @@ def main():
         # outweighs the single lauum launch or the bulk syrk launches (profiles/*_kernel_stats.csv)
         dom = max(("syrk_kernel", "lauum_kernel"), key=lambda k: stages[k]["ms"])
         ach = stages[dom]["tflops"]
-        gram_bytes = N * (N + 64) / 2 * esz + n * d * esz
+        gram_bytes = (N * (N + 64) / 2 * esz + n * d * esz) * S  # lower-triangle 64 x 64 tiles written + inputs read, all sites of the launch
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, gfx950 half-count correction applied: scripts/pmc_summary.py); only valid
         # for the shape those passes were taken at

@@ -192,18 +192,12 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt
   }
   __syncthreads();
   const int ty = t >> 4, tx = t & 15;
-  T fj[4][M::NF], aj[4], bjv[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    aj[b] = saj[tx * 4 + b];
-    bjv[b] = sbj[tx * 4 + b];
-#pragma unroll
-    for (int c = 0; c < M::NF; ++c) fj[b][c] = sfj[c][tx * 4 + b];
-  }
   T acc[M::NTHETA];
 #pragma unroll
   for (int p = 0; p < M::NTHETA; ++p) acc[p] = T(0);
-  // one entry at a time: the derivative expressions are register-hungry, occupancy hides latency
+  // one entry at a time: the derivative expressions are register-hungry, occupancy hides latency.  The column
+  // point's features come from LDS per entry -- a register array indexed by the rolled loop's counter would live in
+  // scratch memory.
 #pragma unroll 1
   for (int a = 0; a < 4; ++a) {
     const long gi = (long)bi * 64 + ty * 4 + a;
@@ -215,11 +209,17 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt
     if (MODE == 0) load4<T>(S + gi * N + (long)bj * 64 + tx * 4, sv);
 #pragma unroll 1
     for (int b = 0; b < 4; ++b) {
-      const long gj = (long)bj * 64 + tx * 4 + b;
+      const int cj = tx * 4 + b;
+      const long gj = (long)bj * 64 + cj;
+      T fj[M::NF];
+#pragma unroll
+      for (int c = 0; c < M::NF; ++c) fj[c] = sfj[c][cj];
+      const T aj = saj[cj];
+      const T svb = b == 0 ? sv[0] : (b == 1 ? sv[1] : (b == 2 ? sv[2] : sv[3]));
       // lower triangle counted once with weight 1 (= 1/2 * 2), diagonal with 1/2, pad with 0
-      T w = MODE == 0 ? sv[b] - ai * aj[b] : -(bi_ * aj[b] + bjv[b] * ai);
+      T w = MODE == 0 ? svb - ai * aj : -(bi_ * aj + sbj[cj] * ai);
       w = (gj > gi || gi >= n) ? T(0) : (gj == gi ? T(0.5) * w : w);
-      (void)M::template pair<true>(fi, fj[b], pre, w, acc);
+      (void)M::template pair<true>(fi, fj, pre, w, acc);
     }
   }
   const int lane = t & 63, wv = t >> 6;

@@ -21,8 +21,60 @@
 
 namespace dgp {
 
-__device__ __forceinline__ void sincospi_t(double x, double* s, double* c) { sincospi(x, s, c); }
-__device__ __forceinline__ void sincospi_t(float x, float* s, float* c) { sincospif(x, s, c); }
+// ---- per-pair elementary functions.  In fp64 the Gram kernels are VALU-bound (SURVEY section 8d prices them against
+// HBM), so every exponent / root of a covariance term goes through a version that drops what cannot happen here
+// (positive or non-finite arguments, denormal results) -- the library versions spend a third of their instructions on
+// those cases.  The periodic term needs no per-pair sine at all: sin and cos of pi t / p are per-POINT features
+// (evaluated in double once per 64 x 64 tile strip) and the pair uses the angle-difference identities.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  // e^x for x <= 0: x = n ln2 + r, |r| <= ln2 / 2, degree-13 Taylor polynomial (truncation 4e-18 relative)
+  x = fmax(x, -708.0);  // below e^-708 = 3e-308 the result only matters as "zero"
+  const double n = __builtin_rint(x * 1.44269504088896340736);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = __builtin_fma(p, r, 1.0 / 479001600.0);
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+__device__ __forceinline__ float exp_nonpos(float x) { return exp(x); }
+
+__device__ __forceinline__ double sqrt_nonneg(double x) {
+  // sqrt of a finite x >= 0 (a scaled squared distance): v_rsq_f64 + two coupled Newton steps, no range scaling
+  x = fmax(x, 1e-280);  // sqrt(0) -> 1e-140: indistinguishable from 0 in every use, and rsq stays finite
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ float sqrt_nonneg(float x) { return sqrt(x); }
+
+// (sin, cos)(pi t / p) of one point, in double whatever T is: the features carry ~1e-16 (fp64) / 6e-8 (fp32) absolute
+// error, uniformly over all pairs -- the direct fp32 evaluation of sin(pi (t_i - t_j) / p) is only that good near
+// the diagonal
+template <typename T>
+__device__ __forceinline__ void phase_features(T t, double inv_p, T* s, T* c) {
+  double sd, cd;
+  sincospi((double)t * inv_p, &sd, &cd);
+  *s = (T)sd;
+  *c = (T)cd;
+}
 
 template <typename T>
 struct MaternTerm {  // value = poly * exp(-q); d value / d lengthscale = dpoly * exp(-q) / l
@@ -48,10 +100,11 @@ __device__ __forceinline__ MaternTerm<T> matern32_q(T q) {
 // ------------------------------------------------------------------------------------------
 template <typename T, int D>
 struct Loadest {
-  static constexpr int NX = D;  // raw coordinate columns (time first)
-  static constexpr int NF = D;  // per-point features
+  static constexpr int NX = D;      // raw coordinate columns (time first)
+  static constexpr int NF = D + 2;  // per-point features: the coordinates, sin and cos of pi t / p
   static constexpr int NTHETA = 2 * D + 5;
   struct Pre {
+    double inv_p_d;
     T os1, inv_lp, inv_p, inv_lm, os2, os3;
     T inv_l2[D - 1];
     T inv_l3[D];
@@ -61,7 +114,8 @@ struct Loadest {
     Pre p;
     p.os1 = (T)th[0];
     p.inv_lp = (T)(1.0 / th[1]);
-    p.inv_p = (T)(1.0 / th[2]);
+    p.inv_p_d = 1.0 / th[2];
+    p.inv_p = (T)p.inv_p_d;
     p.inv_lm = (T)(1.0 / th[3]);
     p.os2 = (T)th[4];
     for (int j = 0; j < D - 1; ++j) p.inv_l2[j] = (T)(1.0 / th[5 + j]);
@@ -69,18 +123,19 @@ struct Loadest {
     for (int j = 0; j < D; ++j) p.inv_l3[j] = (T)(1.0 / th[5 + D + j]);
     return p;
   }
-  static __device__ __forceinline__ void features(const T (&x)[NX], const Pre&, T (&f)[NF]) {
+  static __device__ __forceinline__ void features(const T (&x)[NX], const Pre& p, T (&f)[NF]) {
 #pragma unroll
     for (int j = 0; j < D; ++j) f[j] = x[j];
+    phase_features<T>(x[0], p.inv_p_d, &f[D], &f[D + 1]);
   }
   template <bool GRAD>
   static __device__ __forceinline__ T pair(const T (&fi)[NF], const T (&fj)[NF], const Pre& p, T w, T (&acc)[NTHETA]) {
     const T dt = fi[0] - fj[0];
-    T s, c;
-    sincospi_t(dt * p.inv_p, &s, &c);
+    const T s = fi[D] * fj[D + 1] - fi[D + 1] * fj[D];  // sin(pi dt / p)
+    const T c = fi[D + 1] * fj[D + 1] + fi[D] * fj[D];  // cos(pi dt / p)
     const T s2 = s * s;
     const MaternTerm<T> m5 = matern52(fabs(dt), p.inv_lm);
-    const T e1 = exp(T(-2) * s2 * p.inv_lp - m5.q);
+    const T e1 = exp_nonpos(T(-2) * s2 * p.inv_lp - m5.q);
     const T base1 = e1 * m5.poly;
     T sq2 = T(0), sq3, z3[D], z2[D - 1];
     z3[0] = dt * p.inv_l3[0];
@@ -93,9 +148,9 @@ struct Loadest {
       sq2 += z2[j - 1] * z2[j - 1];
       sq3 += z3[j] * z3[j];
     }
-    const T base2 = exp(T(-0.5) * sq2);
-    const MaternTerm<T> m3 = matern32_q(T(1.73205080756887729353) * sqrt(sq3));
-    const T e3 = exp(-m3.q);
+    const T base2 = exp_nonpos(T(-0.5) * sq2);
+    const MaternTerm<T> m3 = matern32_q(T(1.73205080756887729353) * sqrt_nonneg(sq3));
+    const T e3 = exp_nonpos(-m3.q);
     const T base3 = m3.poly * e3;
     const T k1 = p.os1 * base1, k2 = p.os2 * base2;
     if (GRAD) {
@@ -119,7 +174,7 @@ struct Loadest {
 template <typename T>
 struct Rating {
   static constexpr int NX = 2;  // (time, stage)
-  static constexpr int NF = 3;  // (time, log(stage + 1e-6), gate g(stage))
+  static constexpr int NF = 5;  // (time, log(stage + 1e-6), gate g(stage), sin and cos of pi t / p)
   static constexpr int NTHETA = 16;
   struct Pre {
     T b;
@@ -127,6 +182,7 @@ struct Rating {
     T os_u, inv_ls_u, inv_lt_u;           // cov_bend: Matern52(stage) x Matern52(time)
     T os_b, inv_ls_b;                     // cov_base: Matern52(stage)
     T os_p, inv_lp, inv_p, inv_lm;        // cov_periodic: Periodic(time) x Matern52(time)
+    double inv_p_d;
   };
   static Pre prepare(const double* th) {
     Pre p;
@@ -143,7 +199,8 @@ struct Rating {
     p.inv_ls_b = (T)(1.0 / th[11]);
     p.os_p = (T)th[12];
     p.inv_lp = (T)(1.0 / th[13]);
-    p.inv_p = (T)(1.0 / th[14]);
+    p.inv_p_d = 1.0 / th[14];
+    p.inv_p = (T)p.inv_p_d;
     p.inv_lm = (T)(1.0 / th[15]);
     return p;
   }
@@ -151,6 +208,7 @@ struct Rating {
     f[0] = x[0];
     f[1] = log(x[1] + T(1e-6));                        // LogWarpKernel, kernels.py:374-382
     f[2] = T(1) / (T(1) + exp(T(20) * (x[1] - p.b)));  // SigmoidKernel, kernels.py:311-312 (a = 20)
+    phase_features<T>(x[0], p.inv_p_d, &f[3], &f[4]);
   }
   template <bool GRAD>
   static __device__ __forceinline__ T pair(const T (&fi)[NF], const T (&fj)[NF], const Pre& p, T w, T (&acc)[NTHETA]) {
@@ -162,7 +220,7 @@ struct Rating {
     for (int a = 0; a < 2; ++a) {
       const MaternTerm<T> ms = matern52(adw, p.inv_ls_a[a]);
       const MaternTerm<T> mt = matern32_q(T(1.73205080756887729353) * adt * p.inv_lt_a[a]);
-      const T e = exp(-ms.q - mt.q);
+      const T e = exp_nonpos(-ms.q - mt.q);
       const T base = e * ms.poly * mt.poly;
       lower += p.os_a[a] * base;
       if (GRAD) {
@@ -173,17 +231,17 @@ struct Rating {
       }
     }
     const MaternTerm<T> us = matern52(adw, p.inv_ls_u), ut = matern52(adt, p.inv_lt_u);
-    const T eu = exp(-us.q - ut.q);
+    const T eu = exp_nonpos(-us.q - ut.q);
     const T baseu = eu * us.poly * ut.poly;
     const T upper = p.os_u * baseu;
     const MaternTerm<T> bs = matern52(adw, p.inv_ls_b);
-    const T eb = exp(-bs.q);
+    const T eb = exp_nonpos(-bs.q);
     const T baseb = eb * bs.poly;
-    T s, c;
-    sincospi_t(dt * p.inv_p, &s, &c);
+    const T s = fi[3] * fj[4] - fi[4] * fj[3];  // sin(pi dt / p)
+    const T c = fi[4] * fj[4] + fi[3] * fj[3];  // cos(pi dt / p)
     const T s2 = s * s;
     const MaternTerm<T> pm = matern52(adt, p.inv_lm);
-    const T ep = exp(T(-2) * s2 * p.inv_lp - pm.q);
+    const T ep = exp_nonpos(T(-2) * s2 * p.inv_lp - pm.q);
     const T basep = ep * pm.poly;
     const T kp = p.os_p * basep;
     if (GRAD) {
