@@ -13,6 +13,7 @@
 //   lauum   S = T^T T = K^^-1, one launch, triangular k-range per tile
 //   solve   z = T r, quad = z^T z, alpha = T^T z (bandwidth-bound, deterministic two-stage sums)
 // Flops per fit: N^3/3 (potrf) + N^3/3 (trtri) + N^3/3 (lauum) -- MFMA roofline.
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include "dgp_diag.h"
@@ -533,7 +534,15 @@ static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g
   const int ng = g1 - g0;
   // fewer than ~two rounds (1024) of 128^2 tiles would leave the GPU waiting on the longest one: then use 64^2 tiles
   // (four times as many, at ~87 % of the big tile's rate); a batch multiplies the tile count
-  const bool small = (long)mblk * mblk * ng * bt.B < 1024;
+  // (counting the tiles that exist: the last group of a level is cut off at the matrix edge -- nbk = 40 has a top
+  // level of 8 x 32 blocks, not 32 x 32)
+  const int nbk128 = (int)(N / NB);
+  long tiles = 0;
+  for (int g = g0; g < g1; ++g) {
+    const int rows = nbk128 - (2 * mblk * g + mblk);
+    tiles += (long)(rows < mblk ? (rows > 0 ? rows : 0) : mblk) * mblk;
+  }
+  const bool small = tiles * bt.B < 1024;
   const int m = small ? 2 * mblk : mblk, ntile = (int)(N / (small ? 64 : 128));
   const bool queue = early != nullptr && early->pairs_left > 0 && m * m * ng > early->wg_cap;
   if (!queue) {
@@ -609,10 +618,42 @@ __global__ __launch_bounds__(256, 2) void lauum_kernel(const T* __restrict__ Tm,
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
 }
 
+// the same product in 64 x 64 tiles: four times the workgroups, for matrices whose 128 x 128 tiles do not fill the CUs
+template <typename T>
+__global__ __launch_bounds__(256, 2) void lauum64_kernel(const T* __restrict__ Tm, T* __restrict__ S, long ld, int nb64,
+                                                         long bs) {
+  Tm = site(Tm, bs);
+  S = site(S, bs);
+  using G = TileGemm<T, false, false, 64, 64>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  int bi, bj;
+  tri_decode(blockIdx.x, bi, bj);
+  typename G::acc_t acc[G::MI][G::NI];
+  G::zero(acc);
+  const T* base = Tm + (long)bi * 64 * ld;
+  G::run(base + (long)bi * 64, ld, base + (long)bj * 64, ld, (nb64 - bi) * (64 / 16), smem, acc);
+  T* out = S + (long)bi * 64 * ld + (long)bj * 64;
+  G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
+}
+
+static int lauum64_max_tiles() {
+  static const int v = [] {
+    const char* e = getenv("DGP_LAUUM64");
+    return e ? atoi(e) : 1000;
+  }();
+  return v;
+}
+
 template <typename T>
 int lauum(const T* Tm, long N, T* S, hipStream_t s, Batch bt) {
   const int nbk = (int)(N / NB);
-  lauum_kernel<T><<<dim3((unsigned)(nbk * (nbk + 1) / 2), 1, (unsigned)bt.B), 256, 0, s>>>(Tm, S, N, nbk, bt.ws);
+  const int tiles = nbk * (nbk + 1) / 2;
+  if ((long)tiles * bt.B <= lauum64_max_tiles()) {  // fewer 128-tiles than CUs
+    const int nb64 = 2 * nbk;
+    lauum64_kernel<T><<<dim3((unsigned)(nb64 * (nb64 + 1) / 2), 1, (unsigned)bt.B), 256, 0, s>>>(Tm, S, N, nb64, bt.ws);
+  } else {
+    lauum_kernel<T><<<dim3((unsigned)tiles, 1, (unsigned)bt.B), 256, 0, s>>>(Tm, S, N, nbk, bt.ws);
+  }
   return (int)hipGetLastError();
 }
 

@@ -260,7 +260,7 @@ def test_lookahead_schedule_matches_plain_schedule(n, gpu_device):
     assert (o1[4:4 + P] - g_theta).abs().max() / g_theta.abs().max() < 1e-8
 
 
-@pytest.mark.parametrize("n", [2048, 2200, 2500, 3000, 3300])
+@pytest.mark.parametrize("n", [2048, 2200, 2500, 3000, 3300, 5000])
 def test_early_inverse_matches_in_order_schedule(n, gpu_device):
     """From 16 block columns on, level 2 issues the inverse's level recursion piecewise behind checkpoints of the
     factorisation (third stream).  Same kernels, same operands: the inverse factor and K^^-1 must agree with the
