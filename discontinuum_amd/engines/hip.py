@@ -63,6 +63,7 @@ class MarginalHIP(BaseModel):
         self._current_iteration = 0
         self._plan = None
         self._factor_key = None
+        self._pending_device = None  # (train_x, train_y) whose upload is deferred to the first prediction (fit_many)
 
     # ------------------------------------------------------------------ device plumbing
     def _tensor(self, a):
@@ -80,6 +81,7 @@ class MarginalHIP(BaseModel):
         self._train_y = train_y.to(self.device, self.dtype).contiguous()
         self._plan.set_inputs(self._train_x)
         self._factor_key = None
+        self._pending_device = None
 
     def _prior(self):
         """``self.model(train_x)`` of the reference loop (engines/gpytorch.py:350)."""
@@ -313,9 +315,15 @@ class MarginalHIP(BaseModel):
         self._factor_key = None
 
     # ------------------------------------------------------------------ prediction
+    def _device_ready(self):
+        if getattr(self, "_pending_device", None) is not None:
+            pending, self._pending_device = self._pending_device, None
+            self._setup_device(*pending)
+
     def _ensure_factor(self):
         """Eval-mode cache of the reference's prediction strategy: (L, L^-1, alpha) at the current
         hyperparameters, rebuilt only when a parameter changed."""
+        self._device_ready()
         key = self._param_key()
         if self._factor_key != key:
             with torch.no_grad():
@@ -330,6 +338,7 @@ class MarginalHIP(BaseModel):
 
     def _model_space_predict(self, x: torch.Tensor):
         """(mu, var) in model space -- ``__gpytorch_predict`` of the reference (engines/gpytorch.py:599-626)."""
+        self._device_ready()
         self.model.eval()
         self.likelihood.eval()
         x = x.to(self.device, self.dtype).contiguous()
@@ -377,6 +386,7 @@ class MarginalHIP(BaseModel):
         """Draws from the latent posterior (engines/gpytorch.py:551-593): full m x m covariance
         K** - V^T V with V = L^-1 K(X, X*), its Cholesky factor (our blocked HIP potrf) times N(0, I)."""
         Xnew = torch.tensor(self.dm.Xnew(covariates), dtype=self.dtype).to(self.device).contiguous()
+        self._device_ready()
         self.model.eval()
         self.likelihood.eval()
         with torch.no_grad():

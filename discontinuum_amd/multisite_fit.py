@@ -136,11 +136,12 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
 
     # stacked state of the per-site host modules: every parameter, and the buffers that have one shape across the
     # sites (constraint bounds, prior hyperparameters); site-shaped buffers (the fixed noise) stay the module's own
-    params = {k: torch.stack([dict(h.named_parameters())[k].detach() for h in hosts]).clone().requires_grad_(True)
-              for k, _ in hosts[0].named_parameters()}
+    own_params = [dict(h.named_parameters()) for h in hosts]  # one tree walk per site, not one per (site, name)
+    own_buffers = [dict(h.named_buffers()) for h in hosts]
+    params = {k: torch.stack([own[k].detach() for own in own_params]).clone().requires_grad_(True) for k in own_params[0]}
     buffers = {}
-    for k, b0 in hosts[0].named_buffers():
-        bs = [dict(h.named_buffers())[k] for h in hosts]
+    for k, b0 in own_buffers[0].items():
+        bs = [own[k] for own in own_buffers]
         if all(b.shape == b0.shape for b in bs):
             buffers[k] = torch.stack(bs)
     host0 = hosts[0]
@@ -224,12 +225,12 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
 
     # ---- hand the fitted parameters back to the per-site models
     with torch.no_grad():
-        for b, (m, h) in enumerate(zip(models, hosts)):
-            own = dict(h.named_parameters())
+        for b, (m, own) in enumerate(zip(models, own_params)):
             for k, v in params.items():
                 own[k].copy_(v[b])
             m._current_iteration = iterations - 1
-            m._setup_device(xs[b], ys[b])
+            m._pending_device = (xs[b], ys[b])  # the site's own plan is created when it first predicts
+            m._plan, m._factor_key = None, None
             m.model.eval()
             m.likelihood.eval()
             m.is_fitted = True
