@@ -28,7 +28,7 @@ from ..backend import GPPlan
 from ..gp.lowering import lower
 from ..gp.mll import ExactMarginalLogLikelihood, NotPSDError, predictive_mean
 from ..xr_compat import DataArray
-from .base import BaseModel, is_fitted
+from .base import BaseModel, ModelConfig, is_fitted
 
 
 def _get_optimizer_name(optimizer_obj):
@@ -161,7 +161,10 @@ class MarginalHIP(BaseModel):
         """A model restored from ``save()`` output and re-attached to its data: ready to predict, or to continue
         training with ``fit(..., resume=True)`` (engines/gpytorch.py:47-105)."""
         record = torch.load(f, map_location="cpu", weights_only=False)
-        self = cls()
+        # the reference rebuilds with the default configuration and ignores the one it saved (engines/gpytorch.py:69);
+        # a model trained with transform="standard" would come back in the wrong data space, so the saved one is used
+        saved_config = record.get("model_config")
+        self = cls(model_config=saved_config) if isinstance(saved_config, ModelConfig) else cls()
         x, y, unc = self._attach(covariates, target, target_unc)
         self._fresh_model(x, y, unc)
         self.model.load_state_dict(record["model_state_dict"])
