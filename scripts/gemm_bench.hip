@@ -85,6 +85,14 @@ int main() {
   bench_syrk<double, 1>("f64 syrk store-only K=256", 8192, 256);
   bench_syrk<double, 1>("f64 syrk store-only K=1024", 8192, 1024);
   bench_syrk<double, 0>("f64 syrk RMW K=128 n=4096", 4096, 128);
+  // many rounds of tiles (the batched plan's bulk launches have ~21): steady-state cost of the read-modify-write
+  bench_syrk<double, 0>("f64 syrk RMW K=256 n=16384", 16384, 256);
+  bench_syrk<double, 1>("f64 syrk store-only K=256 n=16384", 16384, 256);
+  bench_syrk<double, 0>("f64 syrk RMW K=512 n=16384", 16384, 512);
+  bench_syrk<double, 1>("f64 syrk store-only K=512 n=16384", 16384, 512);
+  bench_syrk<double, 0>("f64 syrk RMW K=1024 n=16384", 16384, 1024);
+  bench_syrk<double, 1>("f64 syrk store-only K=1024 n=16384", 16384, 1024);
+  bench_syrk<double, 0>("f64 syrk RMW K=4096 n=16384", 16384, 4096);
 
   const long n = 8192;
   bench<double, true, true, 128, 128>("f64 KC/KC", n, 8192);
