@@ -303,12 +303,18 @@ static void tick(dgp_plan* p, int stage, int stop, hipStream_t s) {
 
 template <typename T>
 __global__ void assemble_kernel(const T* scal, const int* info, long n, int ntheta, int zero_grad, T* out, long bs,
-                                long ibs, const int* ns) {
+                                long ibs, const int* ns, const T* alpha) {
   n = site_n(ns, (int)n);
   scal = site(scal, bs);
   info = site(info, ibs);
+  alpha = site(alpha, bs);
   out = site(out, (long)DGP_OUT_LEN);
   const int t = threadIdx.x;
+  // sum_i dNLL/dr_i: what a constant prior mean needs for its gradient, so that the host never has to reduce dr
+  T sdr = T(0);
+  if (!zero_grad)
+    for (long i = t; i < n; i += 64) sdr += alpha[i];
+  sdr = __shfl(wave_sum(sdr), 0, 64);  // lane 0 holds the total: hand it to the lane that writes the slot
   if (t == 0) {
     const T logdet = scal[0], quad = scal[1];
     out[DGP_OUT_NLL] = T(0.5) * quad + T(0.5) * logdet + T(0.5 * 1.83787706640934548356) * (T)n;
@@ -317,7 +323,7 @@ __global__ void assemble_kernel(const T* scal, const int* info, long n, int nthe
     out[DGP_OUT_INFO] = (T)info[0];
   }
   if (zero_grad && t >= DGP_OUT_DTHETA && t < DGP_OUT_LEN) out[t] = T(0);
-  if (!zero_grad && t >= DGP_OUT_DTHETA + ntheta && t < DGP_OUT_LEN) out[t] = T(0);
+  if (!zero_grad && t >= DGP_OUT_DTHETA + ntheta && t < DGP_OUT_LEN) out[t] = t == DGP_OUT_SUM_DR ? sdr : T(0);
 }
 
 template <typename T>
@@ -449,7 +455,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
                                                                                            (T*)dr, bt.ws);
   }
   assemble_kernel<T><<<dim3(1, 1, (unsigned)bt.B), 64, 0, s>>>((const T*)p->scal, p->info, (long)p->n, p->ntheta, !with_grad,
-                                                             (T*)out, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int), bt.ns);
+                                                             (T*)out, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int), bt.ns, (const T*)p->alpha);
   p->have_factor = 1;
   return (int)hipGetLastError();
 }

@@ -18,8 +18,6 @@ from __future__ import annotations
 
 import math
 
-from dataclasses import dataclass
-
 import numpy as np
 import torch
 import tqdm
@@ -39,15 +37,29 @@ def _get_optimizer_name(optimizer_obj):
     return optimizer_obj.__class__.__name__
 
 
-@dataclass
 class PriorSpec:
     """What ``self.model(train_x)`` hands to the marginal likelihood: the device plan, the constrained
-    kernel hyperparameters (host, with grad), the prior mean and the noise diagonal (device, with grad)."""
+    kernel hyperparameters (host, with grad), the prior mean and the noise diagonal (device, with grad), and --
+    when the prior mean is one learned constant -- that constant as a host scalar (``mean_constant``)."""
 
-    plan: object
-    theta: torch.Tensor
-    mean: torch.Tensor
-    noise: torch.Tensor
+    class LazyMean:
+        """The prior mean vector, evaluated only if somebody reads ``spec.mean`` (the marginal likelihood of a
+        constant-mean model does not)."""
+
+        def __init__(self, engine):
+            self.engine = engine
+
+        def __call__(self):
+            return self.engine.model.prior_mean(self.engine._train_x)
+
+    def __init__(self, plan, theta, mean, noise, mean_constant=None):
+        self.plan, self.theta, self._mean, self.noise, self.mean_constant = plan, theta, mean, noise, mean_constant
+
+    @property
+    def mean(self):
+        if isinstance(self._mean, PriorSpec.LazyMean):
+            self._mean = self._mean()
+        return self._mean
 
 
 class MarginalHIP(BaseModel):
@@ -88,9 +100,21 @@ class MarginalHIP(BaseModel):
         return PriorSpec(
             plan=self._plan,
             theta=self._theta_fn(),
-            mean=self.model.prior_mean(self._train_x),
+            mean=PriorSpec.LazyMean(self),
             noise=self.likelihood.train_noise(self._train_x.device, self.dtype),
+            mean_constant=self._constant_mean(),
         )
+
+    def _constant_mean(self):
+        """The learned constant of a ``ConstantMean`` prior mean (loadest-gp), or None for any other mean: the
+        marginal likelihood then needs neither the mean vector nor a device-side reduction for its gradient."""
+        from ..gp.means import ConstantMean
+        from ..gp.models import ExactGP
+
+        module = getattr(self.model, "mean_module", None)
+        if type(module) is ConstantMean and type(self.model).prior_mean is ExactGP.prior_mean:
+            return module.constant
+        return None
 
     def _differentiable_mean(self, x: torch.Tensor):
         """Posterior mean at model-space points ``x`` WITH gradients to every hyperparameter

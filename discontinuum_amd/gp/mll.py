@@ -27,22 +27,28 @@ class _ExactGPNLL(torch.autograd.Function):
     """nll_data(theta, r, noise) = 1/2 r^T K^^-1 r + 1/2 log|K^| + n/2 log 2 pi, K^ = K(theta) + diag(noise)."""
 
     @staticmethod
-    def forward(ctx, plan, theta, r, noise, pending=None):
+    def forward(ctx, plan, theta, r, noise, pending=None, shift=None):
         # `pending` = the (out, dr, dnoise) of a fit_step already launched with these arguments
+        # `shift`   = a constant prior mean c (host scalar tensor) that the caller has already taken off r: its
+        #             gradient -sum_i dNLL/dr_i comes back in the result row, no device reduction, no extra sync
         out, dr, dnoise = pending if pending is not None else plan.fit_step(theta, r, noise)
         host = out.to("cpu", torch.float64)  # the one device->host sync of a fit step
         info = int(host[_lib.OUT_INFO].item())
         if info != 0:
             raise NotPSDError(f"Matrix not positive definite: Cholesky pivot {info} is not positive")
-        ctx.save_for_backward(host[_lib.OUT_DTHETA:_lib.OUT_DTHETA + plan.ntheta].clone(), dr, dnoise)
+        ctx.save_for_backward(host[_lib.OUT_DTHETA:_lib.OUT_DTHETA + plan.ntheta].clone(), dr, dnoise,
+                              host[_lib.OUT_SUM_DR].clone())
         ctx.theta_dtype = theta.dtype
+        ctx.shift_dtype = None if shift is None else shift.dtype
         return host[_lib.OUT_NLL].clone()
 
     @staticmethod
     def backward(ctx, g):
-        dtheta, dr, dnoise = ctx.saved_tensors
-        gd = g.to(dr.device, dr.dtype)
-        return None, (dtheta * g).to(ctx.theta_dtype), dr * gd, dnoise * gd, None
+        dtheta, dr, dnoise, sum_dr = ctx.saved_tensors
+        need = ctx.needs_input_grad  # (plan, theta, r, noise, pending, shift)
+        gd = g.to(dr.device, dr.dtype) if (need[2] or need[3]) else None
+        return (None, (dtheta * g).to(ctx.theta_dtype) if need[1] else None, dr * gd if need[2] else None,
+                dnoise * gd if need[3] else None, None, (-sum_dr * g).to(ctx.shift_dtype) if need[5] else None)
 
 
 class _PredictiveMean(torch.autograd.Function):
@@ -68,16 +74,16 @@ def predictive_mean(plan, theta, r, noise, Xs):
     return _PredictiveMean.apply(plan, theta, r, noise, Xs)
 
 
-def exact_gp_nll(plan, theta, r, noise, pending=None):
+def exact_gp_nll(plan, theta, r, noise, pending=None, shift=None):
     """Differentiable data term with gpytorch's jitter-retry policy. Returns a 0-dim CPU float64 tensor."""
     jitter0 = 1e-8 if plan.dtype == torch.float64 else 1e-6
     try:
-        return _ExactGPNLL.apply(plan, theta, r, noise, pending)
+        return _ExactGPNLL.apply(plan, theta, r, noise, pending, shift)
     except NotPSDError:
         for i in range(3):
             jitter = jitter0 * 10 ** i
             try:
-                val = _ExactGPNLL.apply(plan, theta, r, noise + jitter)
+                val = _ExactGPNLL.apply(plan, theta, r, noise + jitter, None, shift)
             except NotPSDError:
                 continue
             warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", RuntimeWarning, stacklevel=2)
@@ -103,9 +109,13 @@ class ExactMarginalLogLikelihood:
     def __call__(self, output, target):
         """``output`` is the engine's prior spec (plan, theta, mean on device, noise on device)."""
         n = target.shape[0]
-        r = (target - output.mean).contiguous()
+        shift = getattr(output, "mean_constant", None)
+        if shift is not None:  # constant prior mean: a scalar subtraction on the device, its gradient from the result row
+            r = target - float(shift)
+        else:
+            r = (target - output.mean).contiguous()
         noise = output.noise.contiguous()
         pending = output.plan.fit_step(output.theta, r, noise)  # asynchronous: the device starts now ...
         lp = self.log_prior()                                   # ... and the O(P) host algebra runs under it
-        nll = exact_gp_nll(output.plan, output.theta, r, noise, pending)
+        nll = exact_gp_nll(output.plan, output.theta, r, noise, pending, shift)
         return ((-nll + lp) / n).reshape(1)  # shape (1,) like the reference's (1, n)-noise batch

@@ -43,6 +43,7 @@ extern "C" {
 #define DGP_OUT_LOGDET 2 /* log|K^| */
 #define DGP_OUT_INFO 3   /* 0, or 1-based index of the first non-positive pivot */
 #define DGP_OUT_DTHETA 4 /* d NLL / d theta_p, p = 0 .. ntheta-1 */
+#define DGP_OUT_SUM_DR 28 /* sum_i d NLL / d r_i (gradient of a constant prior mean is its negative); fit step only */
 #define DGP_OUT_LEN 32
 
 /* buffers exposed by dgp_plan_buffer (tests and profiling) */

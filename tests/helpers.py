@@ -36,6 +36,7 @@ class OraclePlan:
             return out, torch.zeros(self.n, dtype=self.dtype), torch.zeros(self.n, dtype=self.dtype)
         out[_lib.OUT_NLL] = val
         out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + self.ntheta] = g_theta
+        out[_lib.OUT_SUM_DR] = g_r.sum()
         self._state = (theta, r.double().detach(), noise.double().detach())
         return out, g_r.to(self.dtype), g_noise.to(self.dtype)
 

@@ -122,6 +122,8 @@ def test_fit_step_fp64(model, d, n, lookahead, gpu_device):
     assert (out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + P] - g_theta).abs().max() / g_theta.abs().max() < 1e-8
     assert (dr.cpu() - g_r).abs().max() / g_r.abs().max() < 1e-8
     assert (dnoise.cpu() - g_noise).abs().max() / g_noise.abs().max() < 1e-8
+    # the result row also carries sum_i dNLL/dr_i (the gradient of a constant prior mean, negated)
+    assert abs(out[_lib.OUT_SUM_DR] - g_r.sum()) <= 1e-8 * g_r.abs().sum()
     # repeated call is bitwise reproducible (deterministic reductions)
     out2, dr2, _ = p.fit_step(theta, r.to(dev), noise.to(dev))
     assert torch.equal(out2.cpu(), out) and torch.equal(dr2, dr)
