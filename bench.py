@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--n", "--size", dest="n", type=int, default=8192,
+                    help="observations per site (--size: torch.distributed.run rejects --n as ambiguous with its own options)")
     ap.add_argument("--d", type=int, default=3)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
