@@ -111,7 +111,7 @@ class ExactMarginalLogLikelihood:
         n = target.shape[0]
         shift = getattr(output, "mean_constant", None)
         if shift is not None:  # constant prior mean: a scalar subtraction on the device, its gradient from the result row
-            r = target - float(shift)
+            r = target - float(shift.detach())
         else:
             r = (target - output.mean).contiguous()
         noise = output.noise.contiguous()

@@ -83,7 +83,7 @@ class _BatchedNLL(torch.autograd.Function):
 
 
 def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.05, patience: int = 60,
-             scheduler: bool = True, progress: bool = False):
+             scheduler: bool = True, progress: bool = False, early_stopping: bool = False):
     """Fit ``models[i]`` to ``datasets[i] = (covariates, target[, target_unc])`` for all i at once.  Returns the
     per-site final objectives (a float64 tensor); the models are updated in place (``is_fitted``, parameters, device
     state)."""
@@ -165,6 +165,12 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     sched_patience, factor, threshold, cool, min_lr = max(20, patience // 2), 0.7, 1e-4, 10, 1e-6
     nan_run = torch.zeros(B, dtype=torch.float64)
     last_obj = torch.full((B,), float("nan"), dtype=torch.float64)
+    # early stopping per site (engines/gpytorch.py:407-428): a site that has not improved its best objective by 1e-6
+    # for `patience` of its own steps is frozen -- it keeps its slot in the batched step but is no longer updated
+    live = torch.ones(B, dtype=torch.bool)
+    es_best = torch.full((B,), float("inf"), dtype=torch.float64)
+    stale = torch.zeros(B, dtype=torch.float64)
+    last_iteration = torch.full((B,), iterations - 1, dtype=torch.int64)
 
     def per_site(t, v):  # broadcast a (B,) vector against a stacked parameter
         return v.reshape((B,) + (1,) * (t.dim() - 1))
@@ -183,8 +189,9 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
         noise = noise.contiguous()
         nll = _BatchedNLL.apply(plan, theta, r, noise) if B > 1 else _single(plan, theta, r, noise)
         obj = (nll - lp) / nvec
-        ok = torch.isfinite(obj.detach())
-        nan_run = torch.where(ok, torch.zeros_like(nan_run), nan_run + 1)
+        finite = torch.isfinite(obj.detach())
+        ok = finite & live
+        nan_run = torch.where(finite | ~live, torch.zeros_like(nan_run), nan_run + 1)
         if bool((nan_run > 10).any()):
             raise RuntimeError(f"site {int(torch.argmax(nan_run))}: more than 10 consecutive NaN/Inf objectives "
                                f"at iteration {it + 1}")
@@ -220,15 +227,26 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
             lr = torch.where(reduce & (lr - new_lr > 1e-8), new_lr, lr)
             cooldown = torch.where(reduce, torch.full_like(cooldown, float(cool)), cooldown)
             num_bad = torch.where(reduce, torch.zeros_like(num_bad), num_bad)
+        cur = obj.detach()
+        improved = ok & (cur < es_best - 1e-6)
+        es_best = torch.where(improved, cur, es_best)
+        stale = torch.where(ok, torch.where(improved, torch.zeros_like(stale), stale + 1), stale)
+        if early_stopping:
+            stop = live & (stale >= patience)
+            last_iteration = torch.where(stop, torch.full_like(last_iteration, it), last_iteration)
+            live = live & ~stop
         if progress and (it + 1) % 10 == 0:
-            print(f"iteration {it + 1}: mean objective {float(last_obj.nanmean()):.4f}", flush=True)
+            print(f"iteration {it + 1}: mean objective {float(last_obj.nanmean()):.4f}, {int(live.sum())} sites training",
+                  flush=True)
+        if not bool(live.any()):
+            break
 
     # ---- hand the fitted parameters back to the per-site models
     with torch.no_grad():
         for b, (m, own) in enumerate(zip(models, own_params)):
             for k, v in params.items():
                 own[k].copy_(v[b])
-            m._current_iteration = iterations - 1
+            m._current_iteration = int(last_iteration[b])
             m._pending_device = (xs[b], ys[b])  # the site's own plan is created when it first predicts
             m._plan, m._factor_key = None, None
             m.model.eval()

@@ -212,3 +212,27 @@ def test_fit_many_rating_follows_the_single_site_trajectories(gpu_device):
         ta, _ = a.predict(cov)
         tb, _ = b.predict(cov)
         assert np.allclose(ta.values, tb.values, rtol=1e-6)
+
+
+def test_fit_many_early_stopping_freezes_each_site_where_its_own_fit_stops(gpu_device):
+    """Per-site early stopping: every site must stop at the iteration its own ``model.fit(early_stopping=True)`` stops
+    at (a large learning rate makes the objectives oscillate, so the sites do stop, and at different iterations)."""
+    from discontinuum_amd.loadest_gp import LoadestGP
+    from discontinuum_amd.multisite_fit import fit_many
+
+    sizes, iters, lr, patience = [60, 90, 45, 75], 120, 0.4, 4
+    data = [loadest_dataset(k, seed=700 + i) for i, k in enumerate(sizes)]
+    solo = []
+    for cov, tgt in data:
+        m = LoadestGP()
+        m.fit(cov, tgt, iterations=iters, learning_rate=lr, early_stopping=True, patience=patience)
+        solo.append(m)
+    many = [LoadestGP() for _ in sizes]
+    fit_many(many, data, iterations=iters, learning_rate=lr, early_stopping=True, patience=patience)
+    stops = [m._current_iteration for m in solo]
+    assert [m._current_iteration for m in many] == stops, (stops, [m._current_iteration for m in many])
+    assert min(stops) < iters - 1, stops  # the scenario does exercise the stop
+    for a, b in zip(solo, many):
+        pa = torch.cat([p.detach().reshape(-1) for p in a.model.parameters()])
+        pb = torch.cat([p.detach().reshape(-1) for p in b.model.parameters()])
+        assert (pa - pb).abs().max() < 1e-6, (pa - pb).abs().max()
