@@ -9,10 +9,10 @@ def site(seed):
     r = np.random.default_rng(seed); t = np.sort(r.uniform(-16, 16, n))
     X = np.concatenate([t[:, None], r.standard_normal((n, d - 1))], 1)
     return torch.tensor(X, dtype=dt, device=dev), torch.tensor(r.standard_normal(n), dtype=dt, device=dev)
-nsites = 16 if n > 1024 else 256
+nsites = (64 if n <= 4096 else 16) if n > 1024 else 256
 sites = [site(i) for i in range(nsites)]
 theta1 = [0.6931] * 11
-for B in ((1, 2, 4, 8) if n > 1024 else (1, 8, 32, 128, 256)):
+for B in (((1, 8, 16, 32, 64) if n <= 4096 else (1, 2, 4, 8)) if n > 1024 else (1, 8, 32, 128, 256)):
     p = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=2 if B == 1 else 1, batch=B)
     noise = torch.full((B, n) if B > 1 else (n,), 0.01, dtype=dt, device=dev)
     groups = []
