@@ -5,7 +5,7 @@
 
 One "fit" = one `dgp_fit_step` through the C ABI: Gram build, blocked Cholesky, L^-1, K^^-1, NLL and all
 hyperparameter / residual / noise gradients for one site, inputs resident in HBM (BASELINE.json
-configs[1]).  One "step" = one fit of each of `--sites-per-gpu` (default 8) INDEPENDENT
+configs[1]).  One "step" = one fit of each of `--sites-per-gpu` (default 32) INDEPENDENT
 sites per GPU, carried in lockstep by ONE batched plan (`dgp_plan_set_batch`): every kernel of the step is
 launched once for all of them (gridDim.z = sites) -- the north star's "independent sites / hyperparameter-sample
 batches".  A single fit is bound by the sequential panel chain of its factorisation for half of its time; over
