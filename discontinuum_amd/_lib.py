@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libdgp_hip.so")
 
 F64, F32 = 0, 1
 MODEL_LOADEST, MODEL_RATING = 0, 1
-OUT_NLL, OUT_QUAD, OUT_LOGDET, OUT_INFO, OUT_DTHETA, OUT_SUM_DR, OUT_LEN = 0, 1, 2, 3, 4, 28, 32
+OUT_NLL, OUT_QUAD, OUT_LOGDET, OUT_INFO, OUT_DTHETA, OUT_SUM_DR, OUT_DR_W0, OUT_SUM_DNOISE, OUT_LEN = 0, 1, 2, 3, 4, 28, 29, 31, 32
 BUF_XT, BUF_A, BUF_T, BUF_S, BUF_Z, BUF_ALPHA = range(6)
 BUF_SCAL = 7
 TIME_GRAM, TIME_POTRF, TIME_SYRK_SUM, TIME_SYRK_N, TIME_TRTRI, TIME_LAUUM, TIME_SOLVE, TIME_GRAD, TIME_SYRK_FLOP, TIME_COUNT = range(10)
@@ -47,6 +47,7 @@ SIGNATURES = {
     "dgp_plan_set_batch": (_i, [_vp, _i]),
     "dgp_plan_batch": (_i, [_vp]),
     "dgp_plan_set_site_sizes": (_i, [_vp, C.POINTER(C.c_int64), _vp]),
+    "dgp_plan_set_dr_weights": (_i, [_vp, _vp]),
     "dgp_dist_begin": (_i, [_vp, _vp]),
     "dgp_dist_factor_group": (_i, [_vp, _i, _i, _vp]),
     "dgp_dist_update": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -28,6 +28,7 @@ struct dgp_plan {
   void* pre;              // device scratch for the batch's hyperparameters (B > 8), after the last site
   int pre_ready;          // the Gram build of the current step has uploaded them
   int* nsite;             // device: the sites' own sizes (B > 1), after the hyperparameter scratch
+  const void* dr_w;       // caller's [2][n] weight vectors for the out[DGP_OUT_DR_W0..] reductions, or null
   int64_t n, N;
   size_t elem;
   char* ws;
@@ -180,6 +181,13 @@ int dgp_plan_set_site_sizes(dgp_plan* p, const int64_t* sizes, void* stream) {
   return 0;
 }
 
+int dgp_plan_set_dr_weights(dgp_plan* p, const void* w_dev) {
+  if (!p) return fail(DGP_E_ARG, "dgp_plan_set_dr_weights: null plan");
+  if (w_dev && p->B != 1) return fail(DGP_E_STATE, "dgp_plan_set_dr_weights: single-site plans only");
+  p->dr_w = w_dev;
+  return 0;
+}
+
 int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   if (!p || !dev_ptr) return fail(DGP_E_ARG, "dgp_plan_set_workspace: null");
   const Layout L = layout(p);
@@ -201,6 +209,7 @@ int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   p->info = (int*)(p->ws + L.info);
   p->pre = pre_scratch_bytes(p->B) ? (void*)(p->ws + L.total * (size_t)p->B) : nullptr;
   p->nsite = nullptr;
+  p->dr_w = nullptr;
   if (p->B > 1) {  // every site starts at the full size n
     p->nsite = (int*)(p->ws + L.total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)));
     std::vector<int> full((size_t)p->B, (int)p->n);
@@ -303,18 +312,29 @@ static void tick(dgp_plan* p, int stage, int stop, hipStream_t s) {
 
 template <typename T>
 __global__ void assemble_kernel(const T* scal, const int* info, long n, int ntheta, int zero_grad, T* out, long bs,
-                                long ibs, const int* ns, const T* alpha) {
+                                long ibs, const int* ns, const T* alpha, const T* w, const T* dnoise, long nfull) {
   n = site_n(ns, (int)n);
   scal = site(scal, bs);
   info = site(info, ibs);
   alpha = site(alpha, bs);
+  if (dnoise) dnoise = site(dnoise, nfull);
   out = site(out, (long)DGP_OUT_LEN);
   const int t = threadIdx.x;
-  // sum_i dNLL/dr_i: what a constant prior mean needs for its gradient, so that the host never has to reduce dr
-  T sdr = T(0);
+  // reductions of dNLL/dr (= alpha) and dNLL/dnoise that a parametric prior mean / a learned noise term need for
+  // their gradients, so that the host never reduces device vectors: sum dr, sum dr w0, sum dr w1, sum dnoise
+  T red[4] = {T(0), T(0), T(0), T(0)};
   if (!zero_grad)
-    for (long i = t; i < n; i += 64) sdr += alpha[i];
-  sdr = __shfl(wave_sum(sdr), 0, 64);  // lane 0 holds the total: hand it to the lane that writes the slot
+    for (long i = t; i < n; i += 64) {
+      const T a = alpha[i];
+      red[0] += a;
+      if (w) {
+        red[1] += a * w[i];
+        red[2] += a * w[nfull + i];
+      }
+      if (dnoise) red[3] += dnoise[i];
+    }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[q] = __shfl(wave_sum(red[q]), 0, 64);  // lane 0 holds the total: hand it on
   if (t == 0) {
     const T logdet = scal[0], quad = scal[1];
     out[DGP_OUT_NLL] = T(0.5) * quad + T(0.5) * logdet + T(0.5 * 1.83787706640934548356) * (T)n;
@@ -323,7 +343,7 @@ __global__ void assemble_kernel(const T* scal, const int* info, long n, int nthe
     out[DGP_OUT_INFO] = (T)info[0];
   }
   if (zero_grad && t >= DGP_OUT_DTHETA && t < DGP_OUT_LEN) out[t] = T(0);
-  if (!zero_grad && t >= DGP_OUT_DTHETA + ntheta && t < DGP_OUT_LEN) out[t] = t == DGP_OUT_SUM_DR ? sdr : T(0);
+  if (!zero_grad && t >= DGP_OUT_DTHETA + ntheta && t < DGP_OUT_LEN) out[t] = t >= DGP_OUT_SUM_DR ? red[t - DGP_OUT_SUM_DR] : T(0);
 }
 
 template <typename T>
@@ -455,7 +475,8 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
                                                                                            (T*)dr, bt.ws);
   }
   assemble_kernel<T><<<dim3(1, 1, (unsigned)bt.B), 64, 0, s>>>((const T*)p->scal, p->info, (long)p->n, p->ntheta, !with_grad,
-                                                             (T*)out, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int), bt.ns, (const T*)p->alpha);
+                                                             (T*)out, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int), bt.ns, (const T*)p->alpha,
+                                                             (const T*)(with_grad ? p->dr_w : nullptr), (const T*)(with_grad ? dnoise : nullptr), (long)p->n);
   p->have_factor = 1;
   return (int)hipGetLastError();
 }

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 import tqdm
 
+from .. import _lib
 from ..backend import GPPlan
 from ..gp.lowering import lower
 from ..gp.mll import ExactMarginalLogLikelihood, NotPSDError, predictive_mean
@@ -37,29 +38,54 @@ def _get_optimizer_name(optimizer_obj):
     return optimizer_obj.__class__.__name__
 
 
+class MeanShortcut:
+    """A prior mean / noise model with a handful of parameters that stay on the host.  ``residual_and_noise`` builds
+    y - mu and the noise diagonal on the device WITHOUT autograd (scalars travel as kernel arguments, nothing is copied
+    to the device); ``grads`` maps the reductions the fit step leaves in its result row (``DGP_OUT_SUM_DR``,
+    ``DGP_OUT_DR_W0..``, ``DGP_OUT_SUM_DNOISE``) to d NLL / d param for ``params`` (host tensors with grad)."""
+
+    params: tuple = ()
+
+    def residual_and_noise(self, plan, target):
+        raise NotImplementedError
+
+    def grads(self, row):
+        raise NotImplementedError
+
+
+class ConstantMeanShortcut(MeanShortcut):
+    """mu = c (``ConstantMean``), fixed noise: r = y - c, d NLL / d c = -sum_i d NLL / d r_i."""
+
+    def __init__(self, constant, noise_dev):
+        self.params, self.noise_dev = (constant,), noise_dev
+
+    def residual_and_noise(self, plan, target):
+        return target - float(self.params[0].detach()), self.noise_dev
+
+    def grads(self, row):
+        return (-row[_lib.OUT_SUM_DR],)
+
+
 class PriorSpec:
-    """What ``self.model(train_x)`` hands to the marginal likelihood: the device plan, the constrained
-    kernel hyperparameters (host, with grad), the prior mean and the noise diagonal (device, with grad), and --
-    when the prior mean is one learned constant -- that constant as a host scalar (``mean_constant``)."""
+    """What ``self.model(train_x)`` hands to the marginal likelihood: the device plan, the constrained kernel
+    hyperparameters (host, with grad), the prior mean and the noise diagonal (device, with grad; evaluated when
+    read), and -- for mean / noise models that have one -- the host-side ``shortcut`` the marginal likelihood uses
+    instead of them."""
 
-    class LazyMean:
-        """The prior mean vector, evaluated only if somebody reads ``spec.mean`` (the marginal likelihood of a
-        constant-mean model does not)."""
-
-        def __init__(self, engine):
-            self.engine = engine
-
-        def __call__(self):
-            return self.engine.model.prior_mean(self.engine._train_x)
-
-    def __init__(self, plan, theta, mean, noise, mean_constant=None):
-        self.plan, self.theta, self._mean, self.noise, self.mean_constant = plan, theta, mean, noise, mean_constant
+    def __init__(self, plan, theta, mean, noise, shortcut=None):
+        self.plan, self.theta, self._mean, self._noise, self.shortcut = plan, theta, mean, noise, shortcut
 
     @property
     def mean(self):
-        if isinstance(self._mean, PriorSpec.LazyMean):
+        if callable(self._mean):
             self._mean = self._mean()
         return self._mean
+
+    @property
+    def noise(self):
+        if callable(self._noise):
+            self._noise = self._noise()
+        return self._noise
 
 
 class MarginalHIP(BaseModel):
@@ -100,20 +126,21 @@ class MarginalHIP(BaseModel):
         return PriorSpec(
             plan=self._plan,
             theta=self._theta_fn(),
-            mean=PriorSpec.LazyMean(self),
-            noise=self.likelihood.train_noise(self._train_x.device, self.dtype),
-            mean_constant=self._constant_mean(),
+            mean=lambda: self.model.prior_mean(self._train_x),
+            noise=lambda: self.likelihood.train_noise(self._train_x.device, self.dtype),
+            shortcut=self._mean_shortcut(),
         )
 
-    def _constant_mean(self):
-        """The learned constant of a ``ConstantMean`` prior mean (loadest-gp), or None for any other mean: the
-        marginal likelihood then needs neither the mean vector nor a device-side reduction for its gradient."""
+    def _mean_shortcut(self):
+        """The host-side form of this model's prior mean and noise (``MeanShortcut``) or None.  Here: a learned
+        constant mean with fixed noise (loadest-gp); model packages override it for their own parametric means."""
         from ..gp.means import ConstantMean
         from ..gp.models import ExactGP
 
         module = getattr(self.model, "mean_module", None)
-        if type(module) is ConstantMean and type(self.model).prior_mean is ExactGP.prior_mean:
-            return module.constant
+        if (type(module) is ConstantMean and type(self.model).prior_mean is ExactGP.prior_mean
+                and getattr(self.likelihood, "second_noise_covar", None) is None):
+            return ConstantMeanShortcut(module.constant, self.likelihood.train_noise(self._train_x.device, self.dtype))
         return None
 
     def _differentiable_mean(self, x: torch.Tensor):

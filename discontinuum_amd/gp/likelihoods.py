@@ -40,13 +40,17 @@ class FixedNoiseGaussianLikelihood(nn.Module):
             return None
         return self.second_noise_covar.noise
 
-    def train_noise(self, device, dtype):
-        """Diagonal of Sigma for the n training points (differentiable w.r.t. second_noise)."""
-        # the fixed part is a buffer: keep its device copy across iterations instead of re-uploading n values
+    def train_noise_fixed(self, device, dtype):
+        """The fixed part of the training noise on the device (a buffer: its device copy is kept across iterations
+        instead of re-uploading n values)."""
         key = (str(device), dtype, self.noise.data_ptr(), self.noise._version)
         if getattr(self, "_noise_dev_key", None) != key:
             self._noise_dev, self._noise_dev_key = self.noise.to(device, dtype), key
-        sigma = self._noise_dev
+        return self._noise_dev
+
+    def train_noise(self, device, dtype):
+        """Diagonal of Sigma for the n training points (differentiable w.r.t. second_noise)."""
+        sigma = self.train_noise_fixed(device, dtype)
         if self.second_noise_covar is not None:
             sigma = sigma + self.second_noise.to(device, dtype)
         return sigma

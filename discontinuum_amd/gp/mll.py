@@ -27,28 +27,50 @@ class _ExactGPNLL(torch.autograd.Function):
     """nll_data(theta, r, noise) = 1/2 r^T K^^-1 r + 1/2 log|K^| + n/2 log 2 pi, K^ = K(theta) + diag(noise)."""
 
     @staticmethod
-    def forward(ctx, plan, theta, r, noise, pending=None, shift=None):
+    def forward(ctx, plan, theta, r, noise, pending=None):
         # `pending` = the (out, dr, dnoise) of a fit_step already launched with these arguments
-        # `shift`   = a constant prior mean c (host scalar tensor) that the caller has already taken off r: its
-        #             gradient -sum_i dNLL/dr_i comes back in the result row, no device reduction, no extra sync
         out, dr, dnoise = pending if pending is not None else plan.fit_step(theta, r, noise)
         host = out.to("cpu", torch.float64)  # the one device->host sync of a fit step
         info = int(host[_lib.OUT_INFO].item())
         if info != 0:
             raise NotPSDError(f"Matrix not positive definite: Cholesky pivot {info} is not positive")
-        ctx.save_for_backward(host[_lib.OUT_DTHETA:_lib.OUT_DTHETA + plan.ntheta].clone(), dr, dnoise,
-                              host[_lib.OUT_SUM_DR].clone())
+        ctx.save_for_backward(host[_lib.OUT_DTHETA:_lib.OUT_DTHETA + plan.ntheta].clone(), dr, dnoise)
         ctx.theta_dtype = theta.dtype
-        ctx.shift_dtype = None if shift is None else shift.dtype
         return host[_lib.OUT_NLL].clone()
 
     @staticmethod
     def backward(ctx, g):
-        dtheta, dr, dnoise, sum_dr = ctx.saved_tensors
-        need = ctx.needs_input_grad  # (plan, theta, r, noise, pending, shift)
+        dtheta, dr, dnoise = ctx.saved_tensors
+        need = ctx.needs_input_grad  # (plan, theta, r, noise, pending)
         gd = g.to(dr.device, dr.dtype) if (need[2] or need[3]) else None
         return (None, (dtheta * g).to(ctx.theta_dtype) if need[1] else None, dr * gd if need[2] else None,
-                dnoise * gd if need[3] else None, None, (-sum_dr * g).to(ctx.shift_dtype) if need[5] else None)
+                dnoise * gd if need[3] else None, None)
+
+
+class _RowNLL(torch.autograd.Function):
+    """The same data term for a prior mean / noise model whose few parameters live on the host (``shortcut``, see
+    ``engines/hip.py::MeanShortcut``): the residual and noise vectors were built on the device without autograd, and
+    the parameters' gradients are read off the reductions the fit step leaves in its result row
+    (``DGP_OUT_SUM_DR``, ``DGP_OUT_DR_W0..``, ``DGP_OUT_SUM_DNOISE``) -- no device-side autograd, one sync."""
+
+    @staticmethod
+    def forward(ctx, plan, theta, pending, shortcut, *params):
+        host = pending[0].to("cpu", torch.float64)
+        info = int(host[_lib.OUT_INFO].item())
+        if info != 0:
+            raise NotPSDError(f"Matrix not positive definite: Cholesky pivot {info} is not positive")
+        ctx.save_for_backward(host[_lib.OUT_DTHETA:_lib.OUT_DTHETA + plan.ntheta].clone())
+        ctx.param_grads = shortcut.grads(host)
+        ctx.dtypes = (theta.dtype,) + tuple(p.dtype for p in params)
+        ctx.shapes = tuple(p.shape for p in params)
+        return host[_lib.OUT_NLL].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dtheta,) = ctx.saved_tensors
+        grads = tuple((torch.as_tensor(v, dtype=torch.float64) * g).to(dt).reshape(shape)
+                      for v, dt, shape in zip(ctx.param_grads, ctx.dtypes[1:], ctx.shapes))
+        return (None, (dtheta * g).to(ctx.dtypes[0]), None, None) + grads
 
 
 class _PredictiveMean(torch.autograd.Function):
@@ -74,21 +96,35 @@ def predictive_mean(plan, theta, r, noise, Xs):
     return _PredictiveMean.apply(plan, theta, r, noise, Xs)
 
 
-def exact_gp_nll(plan, theta, r, noise, pending=None, shift=None):
-    """Differentiable data term with gpytorch's jitter-retry policy. Returns a 0-dim CPU float64 tensor."""
+def _with_jitter_retries(plan, first, again):
+    """gpytorch's psd_safe_cholesky policy around a data-term evaluation: ``first()``, then ``again(jitter)`` thrice."""
     jitter0 = 1e-8 if plan.dtype == torch.float64 else 1e-6
     try:
-        return _ExactGPNLL.apply(plan, theta, r, noise, pending, shift)
+        return first()
     except NotPSDError:
         for i in range(3):
             jitter = jitter0 * 10 ** i
             try:
-                val = _ExactGPNLL.apply(plan, theta, r, noise + jitter, None, shift)
+                val = again(jitter)
             except NotPSDError:
                 continue
-            warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", RuntimeWarning, stacklevel=2)
+            warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", RuntimeWarning, stacklevel=3)
             return val
         raise
+
+
+def exact_gp_nll(plan, theta, r, noise, pending=None):
+    """Differentiable data term with gpytorch's jitter-retry policy. Returns a 0-dim CPU float64 tensor."""
+    return _with_jitter_retries(plan, lambda: _ExactGPNLL.apply(plan, theta, r, noise, pending),
+                                lambda jitter: _ExactGPNLL.apply(plan, theta, r, noise + jitter))
+
+
+def exact_gp_nll_row(plan, theta, r, noise, pending, shortcut):
+    """``exact_gp_nll`` for a host-side mean / noise model: gradients from the result row (``_RowNLL``)."""
+    params = shortcut.params
+    return _with_jitter_retries(
+        plan, lambda: _RowNLL.apply(plan, theta, pending, shortcut, *params),
+        lambda jitter: _RowNLL.apply(plan, theta, plan.fit_step(theta, r, noise + jitter), shortcut, *params))
 
 
 class ExactMarginalLogLikelihood:
@@ -109,13 +145,15 @@ class ExactMarginalLogLikelihood:
     def __call__(self, output, target):
         """``output`` is the engine's prior spec (plan, theta, mean on device, noise on device)."""
         n = target.shape[0]
-        shift = getattr(output, "mean_constant", None)
-        if shift is not None:  # constant prior mean: a scalar subtraction on the device, its gradient from the result row
-            r = target - float(shift.detach())
+        shortcut = getattr(output, "shortcut", None)
+        if shortcut is not None:  # mean / noise parameters on the host: device vectors without autograd
+            r, noise = shortcut.residual_and_noise(output.plan, target)
         else:
-            r = (target - output.mean).contiguous()
-        noise = output.noise.contiguous()
+            r, noise = (target - output.mean).contiguous(), output.noise.contiguous()
         pending = output.plan.fit_step(output.theta, r, noise)  # asynchronous: the device starts now ...
         lp = self.log_prior()                                   # ... and the O(P) host algebra runs under it
-        nll = exact_gp_nll(output.plan, output.theta, r, noise, pending, shift)
+        if shortcut is not None:
+            nll = exact_gp_nll_row(output.plan, output.theta, r, noise, pending, shortcut)
+        else:
+            nll = exact_gp_nll(output.plan, output.theta, r, noise, pending)
         return ((-nll + lp) / n).reshape(1)  # shape (1,) like the reference's (1, n)-noise batch

@@ -20,7 +20,8 @@ from torch import nn
 
 from .. import gp
 from ..engines.base import DataMixin, ModelConfig
-from ..engines.hip import MarginalHIP
+from .. import _lib
+from ..engines.hip import MarginalHIP, MeanShortcut
 from ..gp import kernels as K
 from ..gp.constraints import Interval
 from ..gp.means import NoOpMean
@@ -114,6 +115,44 @@ class ExactGPModel(gp.ExactGP):
         self.powerlaw.clamp_c(torch.minimum(train_x[:, STAGE].min(), x[:, STAGE].min()))
 
 
+class _PowerLawShortcut(MeanShortcut):
+    """Host-side form of rating-gp's mean and noise for the marginal likelihood: mu_i = a + b log(s_i - c) and
+    Sigma = diag(y_unc) + sigma_add^2 I, with the reference's in-forward clamps (gpytorch.py:39, 259).  The residual,
+    the noise diagonal and the two weight vectors log(s - c), 1 / (s - c) are a few elementwise device kernels per
+    iteration with the scalars passed by value; the gradients of (a, b, c, sigma_add^2) come from the result row:
+        dNLL/da = -sum dr      dNLL/db = -sum dr log(s - c)      dNLL/dc = b sum dr / (s - c)      dNLL/dsigma^2 = sum dnoise"""
+
+    def __init__(self, engine):
+        # built once per training set (the stage column, its minimum and the fixed noise do not change during a fit)
+        self.powerlaw, self.likelihood = engine.model.powerlaw, engine.likelihood
+        self.stage = engine._train_x[:, STAGE].contiguous()
+        self.stage_min = float(self.stage.min())
+        self.fixed_noise = self.likelihood.train_noise_fixed(self.stage.device, engine.dtype)
+        self.second = None
+        self.b_value = 1.0
+
+    @property
+    def params(self):
+        return (self.powerlaw.a, self.powerlaw.b, self.powerlaw.c, self.second)
+
+    def residual_and_noise(self, plan, target):
+        pw = self.powerlaw
+        pw.b.data.clamp_(1.2, 2.5)
+        pw.clamp_c(self.stage_min)
+        # host tensor with grad: the constraint transform of the raw noise parameter, evaluated once per iteration
+        self.second = self.likelihood.second_noise
+        a, b, c = (float(t.detach()) for t in (pw.a, pw.b, pw.c))
+        self.b_value = b
+        shifted = self.stage - c
+        weights = torch.stack([torch.log(shifted), torch.reciprocal(shifted)])
+        plan.set_dr_weights(weights)
+        return target - a - b * weights[0], self.fixed_noise + float(self.second.detach())
+
+    def grads(self, row):
+        w0 = _lib.OUT_DR_W0
+        return (-row[_lib.OUT_SUM_DR], -row[w0], self.b_value * row[w0 + 1], row[_lib.OUT_SUM_DNOISE])
+
+
 class _MonotonicPenalty:
     """mean(relu(-d mu / d stage)) of the posterior mean on a fresh random grid each call -- time uniform over the
     record, stage log-uniform (denser at low stage), forward difference 1e-3 in model-space stage
@@ -164,6 +203,16 @@ class RatingGPMarginalHIP(RatingDataMixin, MarginalHIP):
         self.likelihood = gp.likelihoods.FixedNoiseGaussianLikelihood(
             noise=fixed, learn_additional_noise=True, noise_prior=HalfNormalPrior(scale=0.03))
         return ExactGPModel(X, y, self.likelihood)
+
+    def _mean_shortcut(self):
+        lik = self.likelihood
+        if (type(self.model) is ExactGPModel and type(self.model.mean_module) is NoOpMean
+                and getattr(lik, "second_noise_covar", None) is not None and hasattr(self._plan, "set_dr_weights")):
+            key = (id(self.model), id(lik), self._train_x.data_ptr(), self._train_x.shape[0])
+            if getattr(self, "_shortcut_key", None) != key:
+                self._shortcut, self._shortcut_key = _PowerLawShortcut(self), key
+            return self._shortcut
+        return None
 
     def fit(self, covariates, target, target_unc=None, iterations=100, optimizer=None, learning_rate=None,
             early_stopping=False, patience=60, scheduler=True, resume=False,

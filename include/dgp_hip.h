@@ -44,6 +44,8 @@ extern "C" {
 #define DGP_OUT_INFO 3   /* 0, or 1-based index of the first non-positive pivot */
 #define DGP_OUT_DTHETA 4 /* d NLL / d theta_p, p = 0 .. ntheta-1 */
 #define DGP_OUT_SUM_DR 28 /* sum_i d NLL / d r_i (gradient of a constant prior mean is its negative); fit step only */
+#define DGP_OUT_DR_W0 29  /* sum_i d NLL / d r_i * w0[i], and w1 in the next slot: see dgp_plan_set_dr_weights */
+#define DGP_OUT_SUM_DNOISE 31 /* sum_i d NLL / d noise_i (gradient of a homoskedastic noise term); needs dnoise_dev */
 #define DGP_OUT_LEN 32
 
 /* buffers exposed by dgp_plan_buffer (tests and profiling) */
@@ -83,6 +85,12 @@ int dgp_plan_batch(const dgp_plan* plan);
  * like the plan's own (identity), its NLL carries sizes[b]/2 log(2 pi), and dr / dnoise are zero beyond sizes[b]. */
 int dgp_plan_set_site_sizes(dgp_plan* plan, const int64_t* sizes_host, void* stream);
 int dgp_plan_set_workspace(dgp_plan* plan, void* dev_ptr, size_t bytes);
+/* Reductions for a parametric prior mean mu(x; phi) that lives on the host side (rating-gp's power law,
+ * src/rating_gp/models/gpytorch.py:28-40): with w_dev = two device vectors [2][n] (e.g. d mu_i / d phi_k), every
+ * following dgp_fit_step also writes sum_i dNLL/dr_i w_k[i] to out[DGP_OUT_DR_W0 + k], next to out[DGP_OUT_SUM_DR]
+ * and out[DGP_OUT_SUM_DNOISE] -- the host gets its mean / noise gradients from the one result row instead of reducing
+ * dr and dnoise itself.  The vectors are read when the step runs; NULL clears.  Single-site plans only. */
+int dgp_plan_set_dr_weights(dgp_plan* plan, const void* w_dev);
 /* Concurrency inside one fit step.  0: everything in order on the caller's stream.  1: the bulk trailing
  * updates of the factorisation run on a second (lowest-priority) stream beside the panel chain.  2 (default):
  * additionally the inverse's level recursion is issued on a third stream behind checkpoints of the

@@ -22,6 +22,9 @@ class OraclePlan:
     def set_inputs(self, X):
         self.X = X.double()
 
+    def set_dr_weights(self, w):
+        self._dr_w = None if w is None else w.double()
+
     def fit_step(self, theta, r, noise):
         self.calls += 1
         theta = torch.as_tensor(theta, dtype=torch.float64).detach()
@@ -37,6 +40,10 @@ class OraclePlan:
         out[_lib.OUT_NLL] = val
         out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + self.ntheta] = g_theta
         out[_lib.OUT_SUM_DR] = g_r.sum()
+        out[_lib.OUT_SUM_DNOISE] = g_noise.sum()
+        if getattr(self, "_dr_w", None) is not None:
+            out[_lib.OUT_DR_W0] = (g_r * self._dr_w[0]).sum()
+            out[_lib.OUT_DR_W0 + 1] = (g_r * self._dr_w[1]).sum()
         self._state = (theta, r.double().detach(), noise.double().detach())
         return out, g_r.to(self.dtype), g_noise.to(self.dtype)
 

@@ -74,8 +74,17 @@ def test_rating_objective_matches_oracle():
     raw[3] = m.likelihood.second_noise_covar.raw_noise.item()
     raw[4] = orc.inv_interval(theta[0], o.b_lo, o.b_hi)
     raw[5:] = orc.inv_softplus(theta[1:])
+    raw.requires_grad_(True)
     ref = o.objective(raw, X, y, yu)
     assert abs(obj.item() - ref.item()) < 1e-10 * max(1, abs(ref.item()))
+    # power-law mean and learned-noise gradients (the engine takes them from the result row's reductions)
+    for p in m.model.parameters():
+        p.grad = None
+    obj.backward()
+    ref.backward()
+    got = torch.stack([mod.powerlaw.a.grad.reshape(()), mod.powerlaw.b.grad.reshape(()), mod.powerlaw.c.grad.reshape(()),
+                       m.likelihood.second_noise_covar.raw_noise.grad.reshape(())])
+    assert torch.allclose(got, raw.grad[:4], rtol=1e-8, atol=1e-12), (got, raw.grad[:4])
 
 
 def test_fit_reduces_objective_and_predicts():

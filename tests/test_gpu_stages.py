@@ -122,8 +122,17 @@ def test_fit_step_fp64(model, d, n, lookahead, gpu_device):
     assert (out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + P] - g_theta).abs().max() / g_theta.abs().max() < 1e-8
     assert (dr.cpu() - g_r).abs().max() / g_r.abs().max() < 1e-8
     assert (dnoise.cpu() - g_noise).abs().max() / g_noise.abs().max() < 1e-8
-    # the result row also carries sum_i dNLL/dr_i (the gradient of a constant prior mean, negated)
+    # the result row also carries sum_i dNLL/dr_i (the gradient of a constant prior mean, negated), sum dnoise, and
+    # -- on request -- dr against two weight vectors (a parametric prior mean's Jacobian)
     assert abs(out[_lib.OUT_SUM_DR] - g_r.sum()) <= 1e-8 * g_r.abs().sum()
+    assert abs(out[_lib.OUT_SUM_DNOISE] - g_noise.sum()) <= 1e-8 * g_noise.abs().sum()
+    assert out[_lib.OUT_DR_W0] == 0 and out[_lib.OUT_DR_W0 + 1] == 0
+    w = torch.randn(2, n, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    p.set_dr_weights(w.to(dev).contiguous())
+    outw = p.fit_step(theta, r.to(dev), noise.to(dev))[0].cpu()
+    for kk in range(2):
+        assert abs(outw[_lib.OUT_DR_W0 + kk] - (g_r * w[kk]).sum()) <= 1e-8 * (g_r * w[kk]).abs().sum()
+    p.set_dr_weights(None)
     # repeated call is bitwise reproducible (deterministic reductions)
     out2, dr2, _ = p.fit_step(theta, r.to(dev), noise.to(dev))
     assert torch.equal(out2.cpu(), out) and torch.equal(dr2, dr)
