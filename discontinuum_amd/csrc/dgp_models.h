@@ -28,7 +28,7 @@ namespace dgp {
 // (evaluated in double once per 64 x 64 tile strip) and the pair uses the angle-difference identities.
 __device__ __forceinline__ double exp_nonpos(double x) {
   // e^x for x <= 0: x = n ln2 + r, |r| <= ln2 / 2, degree-13 Taylor polynomial (truncation 4e-18 relative)
-  x = fmax(x, -708.0);  // below e^-708 = 3e-308 the result only matters as "zero"
+  x = x < -708.0 ? -708.0 : x;  // below e^-708 = 3e-308 the result only matters as "zero"; a NaN stays a NaN
   const double n = __builtin_rint(x * 1.44269504088896340736);
   double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
   r = __builtin_fma(n, -1.90821492927058770002e-10, r);
@@ -52,7 +52,7 @@ __device__ __forceinline__ float exp_nonpos(float x) { return exp(x); }
 
 __device__ __forceinline__ double sqrt_nonneg(double x) {
   // sqrt of a finite x >= 0 (a scaled squared distance): v_rsq_f64 + two coupled Newton steps, no range scaling
-  x = fmax(x, 1e-280);  // sqrt(0) -> 1e-140: indistinguishable from 0 in every use, and rsq stays finite
+  x = x < 1e-280 ? 1e-280 : x;  // sqrt(0) -> 1e-140: indistinguishable from 0 in every use, rsq stays finite; NaN stays NaN
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   const double e = __builtin_fma(-h, g, 0.5);

@@ -359,6 +359,17 @@ def test_nan_input_is_reported_not_hidden(gpu_device):
     out, *_ = p.fit_step(theta, r.to(dev), noise.to(dev))
     out = out.cpu()
     assert (not np.isfinite(out[0].item())) or int(out[3]) != 0
+    # ... in a covariate column (it only enters the squared-distance terms) and in rating-gp's stage column
+    X_bad = X.clone()
+    X_bad[11, 1] = float("nan")
+    p.set_inputs(X_bad.to(dev).contiguous())
+    out = p.fit_step(theta, r.to(dev), noise.to(dev))[0].cpu()
+    assert (not np.isfinite(out[0].item())) or int(out[3]) != 0
+    Xr, rr, nr, tr = make_case("rating", 2, 150, seed=3)
+    Xr[40, 1] = float("nan")
+    pr = plan_for("rating", 2, 150, Xr, torch.float64, dev)
+    out = pr.fit_step(tr, rr.to(dev), nr.to(dev))[0].cpu()
+    assert (not np.isfinite(out[0].item())) or int(out[3]) != 0
 
 
 @pytest.mark.parametrize("model,d,n,B", [("loadest", 3, 700, 3), ("rating", 2, 520, 2), ("loadest", 2, 2300, 4),
