@@ -118,14 +118,13 @@ class GPPlan:
 
     # ------------------------------------------------------------------ hot path
     def set_dr_weights(self, w):
-        """Two device vectors (2, n) for which every following fit step also returns sum_i dNLL/dr_i w_k[i] in
-        ``out[OUT_DR_W0 + k]`` (None clears).  The tensor is kept alive by the plan."""
+        """Two device vectors (2, n) -- (batch, 2, n) for a batched plan -- for which every following fit step also
+        returns sum_i dNLL/dr_i w_k[i] in ``out[..., OUT_DR_W0 + k]`` (None clears).  The plan keeps the tensor alive."""
         if w is not None:
-            if self.batch != 1:
-                raise ValueError("dr weights are supported by single-site plans only")
-            if not (torch.is_tensor(w) and w.is_cuda and w.dtype == self.dtype and tuple(w.shape) == (2, self.n)
+            shape = (2, self.n) if self.batch == 1 else (self.batch, 2, self.n)
+            if not (torch.is_tensor(w) and w.is_cuda and w.dtype == self.dtype and tuple(w.shape) == shape
                     and w.is_contiguous()):
-                raise ValueError(f"dr weights must be a contiguous (2, {self.n}) {self.dtype} CUDA tensor")
+                raise ValueError(f"dr weights must be a contiguous {shape} {self.dtype} CUDA tensor")
         self._dr_w = w
         _lib.check(self.lib.dgp_plan_set_dr_weights(self._h, _ptr(w) if w is not None else None), "dgp_plan_set_dr_weights")
 

@@ -183,7 +183,6 @@ int dgp_plan_set_site_sizes(dgp_plan* p, const int64_t* sizes, void* stream) {
 
 int dgp_plan_set_dr_weights(dgp_plan* p, const void* w_dev) {
   if (!p) return fail(DGP_E_ARG, "dgp_plan_set_dr_weights: null plan");
-  if (w_dev && p->B != 1) return fail(DGP_E_STATE, "dgp_plan_set_dr_weights: single-site plans only");
   p->dr_w = w_dev;
   return 0;
 }
@@ -318,6 +317,7 @@ __global__ void assemble_kernel(const T* scal, const int* info, long n, int nthe
   info = site(info, ibs);
   alpha = site(alpha, bs);
   if (dnoise) dnoise = site(dnoise, nfull);
+  if (w) w = site(w, 2 * nfull);  // [site][2][n]
   out = site(out, (long)DGP_OUT_LEN);
   const int t = threadIdx.x;
   // reductions of dNLL/dr (= alpha) and dNLL/dnoise that a parametric prior mean / a learned noise term need for

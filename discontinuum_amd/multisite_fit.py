@@ -58,28 +58,37 @@ class _HostSide(nn.Module):
 
 
 class _BatchedNLL(torch.autograd.Function):
-    """Data terms of B sites from one batched ``dgp_fit_step``; sites that fail come back as NaN with zero gradient."""
+    """Data terms of B sites from one batched ``dgp_fit_step``; sites that fail come back as NaN with zero gradient.
+    The residual and noise vectors arrive without autograd; the gradients of the mean / noise parameters
+    (``extras``, (B, E) on the host) are read off the reductions in each site's result row -- like the single-site
+    engine (``engines/hip.py::MeanShortcut``): no device-side autograd, one device->host copy per iteration."""
 
     @staticmethod
-    def forward(ctx, plan, theta, r, noise):
-        out, dr, dnoise = plan.fit_step(theta, r, noise)
+    def forward(ctx, plan, theta, r, noise, extras, family):
+        if plan.batch == 1:
+            out = plan.fit_step(theta[0], r[0].contiguous(), noise[0].contiguous())[0].reshape(1, -1)
+        else:
+            out = plan.fit_step(theta, r, noise)[0]
         host = out.to("cpu", torch.float64)
         ok = (host[:, _lib.OUT_INFO] == 0) & torch.isfinite(host[:, _lib.OUT_NLL])
-        dtheta = torch.nan_to_num(host[:, _lib.OUT_DTHETA:_lib.OUT_DTHETA + plan.ntheta], nan=0.0, posinf=0.0, neginf=0.0)
-        dtheta = dtheta * ok[:, None]
-        okd = ok.to(dr.device)[:, None]
-        dr = torch.nan_to_num(dr, nan=0.0, posinf=0.0, neginf=0.0) * okd
-        dnoise = torch.nan_to_num(dnoise, nan=0.0, posinf=0.0, neginf=0.0) * okd
-        ctx.save_for_backward(dtheta, dr, dnoise)
-        ctx.theta_dtype = theta.dtype
+        clean = torch.nan_to_num(host, nan=0.0, posinf=0.0, neginf=0.0) * ok[:, None]
+        dtheta = clean[:, _lib.OUT_DTHETA:_lib.OUT_DTHETA + plan.ntheta]
+        sum_dr = clean[:, _lib.OUT_SUM_DR]
+        if family == "rating":  # (a, b, c, second_noise): mu = a + b log(s - c), Sigma = fixed + second_noise
+            w0 = _lib.OUT_DR_W0
+            dextras = torch.stack([-sum_dr, -clean[:, w0], extras[:, 1].detach() * clean[:, w0 + 1],
+                                   clean[:, _lib.OUT_SUM_DNOISE]], dim=1)
+        else:                   # (c,): mu = c
+            dextras = -sum_dr[:, None]
+        ctx.save_for_backward(dtheta, dextras)
+        ctx.dtypes = (theta.dtype, extras.dtype)
         return torch.where(ok, host[:, _lib.OUT_NLL], torch.full_like(host[:, 0], float("nan")))
 
     @staticmethod
     def backward(ctx, g):
-        dtheta, dr, dnoise = ctx.saved_tensors
-        g = torch.nan_to_num(g, nan=0.0)
-        gd = g.to(dr.device, dr.dtype)[:, None]
-        return None, (dtheta * g[:, None]).to(ctx.theta_dtype), dr * gd, dnoise * gd
+        dtheta, dextras = ctx.saved_tensors
+        g = torch.nan_to_num(g, nan=0.0)[:, None]
+        return None, (dtheta * g).to(ctx.dtypes[0]), None, None, (dextras * g).to(ctx.dtypes[1]), None
 
 
 def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.05, patience: int = 60,
@@ -126,11 +135,16 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
         stage_floor = torch.stack([x[:, 1].min() for x in xs]).to(torch.float64) - 1e-6
 
     def mean_and_noise(extras):
-        """Prior mean and noise diagonal of every site in its slots (device, differentiable w.r.t. ``extras``)."""
-        e = extras.to(device, dtype)
+        """Prior mean and noise diagonal of every site in its slots, built on the device WITHOUT autograd from the
+        current values of ``extras``; for rating-gp also the two weight vectors whose reductions give the power
+        law's gradients (``dgp_plan_set_dr_weights``)."""
+        e = extras.detach().to(device, dtype)
         if family == "rating":
-            mean = e[:, 0:1] + e[:, 1:2] * torch.log(stage - e[:, 2:3])
-            return mean, fixed_noise + e[:, 3:4]
+            shifted = stage - e[:, 2:3]
+            log_s = torch.log(shifted)
+            weights = torch.stack([log_s, torch.reciprocal(shifted)], dim=1).contiguous()  # (B, 2, n)
+            plan.set_dr_weights(weights if B > 1 else weights[0].contiguous())
+            return e[:, 0:1] + e[:, 1:2] * log_s, fixed_noise + e[:, 3:4]
         return e[:, 0:1].expand(B, n), fixed_noise
     plan.set_inputs(X if B > 1 else X[0].contiguous())
 
@@ -187,7 +201,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
         mean, noise = mean_and_noise(extras)
         r = (Y - mean).contiguous()
         noise = noise.contiguous()
-        nll = _BatchedNLL.apply(plan, theta, r, noise) if B > 1 else _single(plan, theta, r, noise)
+        nll = _BatchedNLL.apply(plan, theta, r, noise, extras, family)
         obj = (nll - lp) / nvec
         finite = torch.isfinite(obj.detach())
         ok = finite & live
@@ -253,13 +267,6 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
             m.likelihood.eval()
             m.is_fitted = True
     return last_obj
-
-
-def _single(plan, theta, r, noise):
-    """B = 1: the unbatched plan takes unbatched arrays."""
-    from .gp.mll import exact_gp_nll
-
-    return exact_gp_nll(plan, theta[0], r[0].contiguous(), noise[0].contiguous()).reshape(1)
 
 
 __all__ = ["fit_many"]

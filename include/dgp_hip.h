@@ -89,7 +89,7 @@ int dgp_plan_set_workspace(dgp_plan* plan, void* dev_ptr, size_t bytes);
  * src/rating_gp/models/gpytorch.py:28-40): with w_dev = two device vectors [2][n] (e.g. d mu_i / d phi_k), every
  * following dgp_fit_step also writes sum_i dNLL/dr_i w_k[i] to out[DGP_OUT_DR_W0 + k], next to out[DGP_OUT_SUM_DR]
  * and out[DGP_OUT_SUM_DNOISE] -- the host gets its mean / noise gradients from the one result row instead of reducing
- * dr and dnoise itself.  The vectors are read when the step runs; NULL clears.  Single-site plans only. */
+ * dr and dnoise itself.  The vectors are read when the step runs; NULL clears.  Batched plans: [batch][2][n]. */
 int dgp_plan_set_dr_weights(dgp_plan* plan, const void* w_dev);
 /* Concurrency inside one fit step.  0: everything in order on the caller's stream.  1: the bulk trailing
  * updates of the factorisation run on a second (lowest-priority) stream beside the panel chain.  2 (default):

@@ -236,3 +236,31 @@ def test_fit_many_early_stopping_freezes_each_site_where_its_own_fit_stops(gpu_d
         pa = torch.cat([p.detach().reshape(-1) for p in a.model.parameters()])
         pb = torch.cat([p.detach().reshape(-1) for p in b.model.parameters()])
         assert (pa - pb).abs().max() < 1e-6, (pa - pb).abs().max()
+
+
+def test_fit_many_with_a_single_site_uses_the_unbatched_plan(gpu_device):
+    """One site through ``fit_many`` (unbatched plan, (2, n) weight vectors) ends where a batch of two puts it."""
+    from discontinuum_amd.multisite_fit import fit_many
+    from discontinuum_amd.rating_gp import RatingGP
+
+    class Seeded(RatingGP):
+        seed = 0
+
+        def build_model(self, *args):
+            torch.manual_seed(self.seed)
+            return super().build_model(*args)
+
+    data = [rating_dataset(64, seed=41), rating_dataset(50, seed=42)]
+
+    def new(i):
+        m = Seeded()
+        m.seed = 77 + i
+        return m
+
+    pair = [new(0), new(1)]
+    fit_many(pair, data, iterations=25)
+    alone = [new(0)]
+    fit_many(alone, data[:1], iterations=25)
+    pa = torch.cat([p.detach().reshape(-1) for p in pair[0].model.parameters()])
+    pb = torch.cat([p.detach().reshape(-1) for p in alone[0].model.parameters()])
+    assert (pa - pb).abs().max() < 1e-6, (pa - pb).abs().max()
