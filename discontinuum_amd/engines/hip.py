@@ -30,6 +30,22 @@ from ..xr_compat import DataArray
 from .base import BaseModel, ModelConfig, is_fitted
 
 
+def _clip_grad_norm(params, max_norm):
+    """``torch.nn.utils.clip_grad_norm_(params, max_norm)`` (2-norm, in place) for a few dozen scalar-sized host
+    gradients: the same arithmetic -- scale by min(1, max_norm / (norm + 1e-6)) -- through one flat reduction instead
+    of the foreach machinery (85 -> 30 us per iteration).  Returns the total norm as a float."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return 0.0
+    flat = grads[0].reshape(-1) if len(grads) == 1 else torch.cat([g.reshape(-1) for g in grads])
+    total = float(torch.linalg.vector_norm(flat))
+    coef = max_norm / (total + 1e-6)
+    if not coef >= 1.0:  # a NaN norm scales by NaN, an infinite one by 0, exactly like torch's clamped coefficient
+        for g in grads:
+            g.mul_(coef)
+    return total
+
+
 def _get_optimizer_name(optimizer_obj):
     if isinstance(optimizer_obj, torch.optim.AdamW):
         return "adamw"
@@ -333,7 +349,7 @@ class MarginalHIP(BaseModel):
                     continue
                 bad_in_a_row = 0
                 objective.backward()
-                total_norm = torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+                total_norm = _clip_grad_norm(params, 1.0)
                 # the reference scans every p.grad for NaN after clipping (engines/gpytorch.py:387-392); a clipped
                 # gradient holds a NaN exactly when the pre-clip norm is NaN or Inf (Inf * 0 = NaN), so one scalar says it
                 grads_broken = not math.isfinite(float(total_norm))

@@ -192,3 +192,25 @@ def test_nan_objective_guard():
     with pytest.raises(RuntimeError, match="not psd"):
         m.fit(cov, tgt, iterations=30, resume=True)
     assert m.is_fitted
+
+
+def test_gradient_clipping_matches_torch():
+    """The loop's own clip (one flat reduction) against ``torch.nn.utils.clip_grad_norm_``, broken gradients included."""
+    from discontinuum_amd.engines.hip import _clip_grad_norm
+
+    for case in range(8):
+        torch.manual_seed(case)
+        ours = [torch.nn.Parameter(torch.randn(s, dtype=torch.float64)) for s in [(), (1,), (1, 3), (2,), (1, 1)]]
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+        for p, q in zip(ours, ref):
+            g = torch.randn_like(p) * (10 if case % 2 else 0.01)
+            if case == 6:
+                g.reshape(-1)[0] = float("nan")
+            if case == 7:
+                g.reshape(-1)[0] = float("inf")
+            p.grad, q.grad = g.clone(), g.clone()
+        a = _clip_grad_norm(ours, 1.0)
+        b = float(torch.nn.utils.clip_grad_norm_(ref, 1.0))
+        assert (a == b) or (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-15 * abs(b)
+        for p, q in zip(ours, ref):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-15, atol=0, equal_nan=True)
