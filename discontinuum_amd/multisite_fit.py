@@ -113,6 +113,13 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     d = xs[0].shape[1]
     if any(x.shape[1] != d for x in xs) or any(h.name != hosts[0].name for h in hosts):
         raise ValueError("fit_many needs sites of one model family and one input dimension")
+    # the mean / noise models this loop knows: loadest-gp (learned constant, fixed noise) and rating-gp (power law,
+    # fixed + one learned noise term); anything else would silently lose the gradients of its extra parameters
+    for m in models:
+        learned_noise = getattr(m.likelihood, "second_noise_covar", None) is not None
+        if (hosts[0].name == "rating") != learned_noise or (hosts[0].name == "rating") != hasattr(m.model, "powerlaw"):
+            raise NotImplementedError("fit_many supports the loadest-gp and rating-gp mean / noise models; "
+                                      "train this model with its own fit()")
     sizes = [x.shape[0] for x in xs]
     n = max(sizes)
     plan = GPPlan(hosts[0].name, n, d, dtype=dtype, device=device, lookahead=1 if B > 1 else 2, batch=B)
