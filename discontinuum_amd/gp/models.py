@@ -1,7 +1,6 @@
 """``ExactGP`` container: training data + likelihood + the user's mean / covariance modules."""
 from __future__ import annotations
 
-import torch
 from torch import nn
 
 
