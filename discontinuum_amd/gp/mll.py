@@ -135,11 +135,58 @@ class ExactMarginalLogLikelihood:
         self._priors = prior_closures(model)
         if likelihood is not None and not any(likelihood is m for m in model.modules()):
             self._priors += prior_closures(likelihood)
+        self._group_priors()
+
+    def _group_priors(self):
+        """Priors of one family are evaluated together: their constrained values are concatenated and the family's
+        log-density is a handful of vector operations with the hyperparameters (constants during a fit) expanded per
+        element -- a dozen autograd nodes per iteration instead of six per prior.  Other prior classes are evaluated
+        one by one."""
+        import math
+
+        from .priors import GammaPrior, HalfNormalPrior, NormalPrior
+
+        with torch.no_grad():
+            sizes = [int(closure(mod).numel()) for _prior, closure, mod in self._priors]
+        self._groups, self._loose, self._prior_const = {}, [], 0.0
+        half_log_2pi = 0.5 * math.log(2.0 * math.pi)
+        for kind in (GammaPrior, HalfNormalPrior, NormalPrior):
+            idx = [i for i, (prior, _c, _m) in enumerate(self._priors) if type(prior) is kind]
+            if not idx:
+                continue
+
+            def per_element(name):
+                return torch.cat([getattr(self._priors[i][0], name).detach().to(torch.float64).reshape(1).expand(sizes[i])
+                                  for i in idx])
+
+            if kind is GammaPrior:
+                a, b = per_element("concentration"), per_element("rate")
+                self._prior_const += float((a * torch.log(b) - torch.lgamma(a)).sum())
+                self._groups["gamma"] = (idx, a - 1.0, b)
+            elif kind is HalfNormalPrior:
+                scale = per_element("scale")
+                self._prior_const += float((math.log(2.0) - torch.log(scale) - half_log_2pi).sum())
+                self._groups["half_normal"] = (idx, 1.0 / scale, None)
+            else:
+                loc, scale = per_element("loc"), per_element("scale")
+                self._prior_const += float((-torch.log(scale) - half_log_2pi).sum())
+                self._groups["normal"] = (idx, 1.0 / scale, loc)
+        grouped = {i for idx, _a, _b in self._groups.values() for i in idx}
+        self._loose = [i for i in range(len(self._priors)) if i not in grouped]
 
     def log_prior(self):
-        lp = torch.zeros((), dtype=torch.float64)
-        for prior, closure, mod in self._priors:
-            lp = lp + prior.log_prob(closure(mod)).sum()
+        values = [closure(mod).reshape(-1) for _prior, closure, mod in self._priors]
+        lp = torch.full((), self._prior_const, dtype=torch.float64)
+        for name, (idx, p, q) in self._groups.items():
+            x = values[idx[0]] if len(idx) == 1 else torch.cat([values[i] for i in idx])
+            if name == "gamma":          # (a - 1) log x - b x
+                lp = lp + (p * torch.log(x) - q * x).sum()
+            elif name == "half_normal":  # -1/2 (x / s)^2
+                lp = lp - 0.5 * ((x * p) ** 2).sum()
+            else:                        # -1/2 ((x - loc) / s)^2
+                lp = lp - 0.5 * (((x - q) * p) ** 2).sum()
+        for i in self._loose:
+            lp = lp + self._priors[i][0].log_prob(values[i]).sum()
         return lp
 
     def __call__(self, output, target):
