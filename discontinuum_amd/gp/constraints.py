@@ -50,3 +50,9 @@ class Positive(GreaterThan):
 
     def __init__(self):
         super().__init__(0.0)
+
+    def transform(self, raw):
+        return torch.nn.functional.softplus(raw)  # without GreaterThan's "+ 0": one autograd node less per value
+
+    def inverse_transform(self, value):
+        return _inv_softplus(torch.as_tensor(value, dtype=torch.float64))
