@@ -373,7 +373,7 @@ class MarginalHIP(BaseModel):
                     note = f"obj={value:.4f}, lr={optimizer_obj.param_groups[0]['lr']:.1e}"
                     if penalty is not None and bool(torch.isfinite(penalty).all()):
                         note += f", pen={float(penalty.detach()):.3e}"
-                    bar.set_postfix_str(note)
+                    bar.set_postfix_str(note, refresh=False)  # shown at the bar's own refresh interval, not forced every iteration
                 if stop:
                     break
         except KeyboardInterrupt:
