@@ -214,3 +214,34 @@ def test_gradient_clipping_matches_torch():
         assert (a == b) or (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-15 * abs(b)
         for p, q in zip(ours, ref):
             assert torch.allclose(p.grad, q.grad, rtol=1e-15, atol=0, equal_nan=True)
+
+
+def test_lean_optimizer_steps_are_torchs_bit_for_bit():
+    """The loop's Adam / AdamW (torch's multi-tensor arithmetic without ``Optimizer.step``'s bookkeeping) against
+    ``torch.optim``: parameters and optimiser state identical after 60 steps with a learning-rate change, a parameter
+    without gradient falls back to torch's own step."""
+    from discontinuum_amd.engines.hip import _LeanAdam, _LeanAdamW
+
+    for lean, ref, wd in ((_LeanAdam, torch.optim.Adam, 1e-4), (_LeanAdamW, torch.optim.AdamW, 1e-2)):
+        torch.manual_seed(0)
+        ours = [torch.nn.Parameter(torch.randn(s, dtype=torch.float64)) for s in [(), (1,), (1, 3), (2,), (1, 1)]]
+        theirs = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+        a = lean(ours, lr=0.05, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, foreach=True)
+        b = ref(theirs, lr=0.05, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, foreach=True)
+        for it in range(60):
+            for p, q in zip(ours, theirs):
+                g = torch.randn_like(p)
+                p.grad, q.grad = g.clone(), g.clone()
+            if it == 30:
+                a.param_groups[0]["lr"] = b.param_groups[0]["lr"] = 0.035
+            if it == 45:  # a parameter without gradient: torch skips it, and so must we
+                ours[2].grad = theirs[2].grad = None
+            a.step()
+            b.step()
+        for p, q in zip(ours, theirs):
+            assert torch.equal(p.detach(), q.detach())
+        sa, sb = a.state_dict(), b.state_dict()
+        assert sa["param_groups"] == sb["param_groups"]
+        for k in sb["state"]:
+            for name in ("step", "exp_avg", "exp_avg_sq"):
+                assert torch.equal(sa["state"][k][name], sb["state"][k][name]), (k, name)
