@@ -16,4 +16,4 @@ m.fit(cov, tgt, iterations=5)
 torch.cuda.synchronize(); t0 = time.perf_counter(); m.fit(cov, tgt, iterations=200); torch.cuda.synchronize()
 print("ms per iteration:", (time.perf_counter() - t0) * 5)
 pr = cProfile.Profile(); pr.enable(); m.fit(cov, tgt, iterations=200); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)
