@@ -30,64 +30,116 @@ from ..xr_compat import DataArray
 from .base import BaseModel, ModelConfig, is_fitted
 
 
+class _FlatState:
+    """The optimiser state of all parameters in three flat buffers; ``state[p]['exp_avg' | 'exp_avg_sq' | 'step']``
+    are views into them, so ``state_dict()`` still holds torch's per-parameter layout.  ``load_state_dict`` and
+    torch's own ``step`` (the fallback) invalidate it: it is then rebuilt from whatever the state holds."""
+
+    def __init__(self, params, state):
+        self.sizes = [int(p.numel()) for p in params]
+        self.shapes = [p.shape for p in params]
+        self.exp_avg = torch.cat([state[p]["exp_avg"].detach().reshape(-1) for p in params])
+        self.exp_avg_sq = torch.cat([state[p]["exp_avg_sq"].detach().reshape(-1) for p in params])
+        self.steps = torch.stack([state[p]["step"].detach().reshape(()) for p in params])
+        self.count = int(self.steps[0])  # equal for all parameters (checked by the caller)
+        self.param_views = [p.detach().view(-1) for p in params]  # same storage as the parameters, flat shapes
+        offset = 0
+        for k, (p, n, shape) in enumerate(zip(params, self.sizes, self.shapes)):
+            state[p]["exp_avg"] = self.exp_avg[offset:offset + n].view(shape)
+            state[p]["exp_avg_sq"] = self.exp_avg_sq[offset:offset + n].view(shape)
+            state[p]["step"] = self.steps[k]
+            offset += n
+
+
+def _flat_state(opt, params):
+    """The optimiser's ``_FlatState``, (re)built if needed; None if the state is not one the fast path handles."""
+    flat = opt.__dict__.get("_flat_state")
+    if flat is not None:
+        # the flat parameter views must still be the parameters' storage (someone may have reassigned ``p.data``)
+        if (flat.param_views[0].data_ptr() == params[0].data_ptr()
+                and flat.param_views[-1].data_ptr() == params[-1].data_ptr()):
+            return flat
+    state, first = opt.state, None
+    for p in params:
+        st = state.get(p)
+        if not st or not torch.is_tensor(st.get("step")) or "exp_avg" not in st or "exp_avg_sq" not in st:
+            return None  # before torch's first step has created the state
+        if first is None:
+            first = float(st["step"])
+        elif float(st["step"]) != first:
+            return None  # parameters that have taken different numbers of steps
+    flat = opt.__dict__["_flat_state"] = _FlatState(params, state)
+    return flat
+
+
 def _lean_step(opt, decoupled):
-    """One Adam / AdamW step with torch's multi-tensor arithmetic (``torch.optim.adam._multi_tensor_adam`` without
-    amsgrad / maximize / capturable) minus the per-step bookkeeping of ``Optimizer.step`` -- hooks, profiler ranges,
-    group re-initialisation -- which for a dozen scalar-sized host parameters is three quarters of its 200 us.
-    State layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter) and results are those of torch's optimiser,
-    so ``state_dict()`` / ``load_state_dict()`` and checkpoints are unaffected.  Returns False if the fast path does
-    not apply (first step, a parameter without gradient, several groups): the caller then takes torch's own step."""
+    """One Adam / AdamW step with the arithmetic of ``torch.optim.adam._multi_tensor_adam`` (no amsgrad / maximize /
+    capturable), element for element, on FLAT views of the state: a dozen scalar-sized host parameters cost torch's
+    ``Optimizer.step`` about 200 us, three quarters of it bookkeeping and per-tensor dispatch; this is a dozen vector
+    operations.  ``state_dict()`` / ``load_state_dict()`` and checkpoints keep torch's per-parameter layout
+    (``_FlatState``), and parameters and state stay bit-identical to torch's (tests/test_engine_cpu.py).  Returns False
+    if the fast path does not apply (first step, a parameter without gradient, several groups, unequal step counts):
+    the caller then takes torch's own step."""
     if len(opt.param_groups) != 1:
         return False
     group = opt.param_groups[0]
     params = group["params"]
-    state = opt.state
     if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable"):
         return False
-    grads, exp_avgs, exp_avg_sqs, steps = [], [], [], []
     for p in params:
-        st = state.get(p)
-        if p.grad is None or not st or p.grad.is_sparse or not torch.is_tensor(st.get("step")):
+        if p.grad is None or p.grad.is_sparse:
             return False
-        grads.append(p.grad)
-        exp_avgs.append(st["exp_avg"])
-        exp_avg_sqs.append(st["exp_avg_sq"])
-        steps.append(st["step"])
-    step = float(steps[0]) + 1.0
-    if any(float(t) + 1.0 != step for t in steps[1:]):  # parameters that have taken different numbers of steps
-        return False
-    beta1, beta2 = group["betas"]
-    lr, wd, eps = float(group["lr"]), group["weight_decay"], group["eps"]
     with torch.no_grad():
-        torch._foreach_add_(steps, 1)
+        flat = _flat_state(opt, params)
+        if flat is None:
+            return False
+        beta1, beta2 = group["betas"]
+        lr, wd, eps = float(group["lr"]), group["weight_decay"], group["eps"]
+        grad = torch.cat([p.grad.reshape(-1) for p in params])
+        flat.steps += 1
+        flat.count += 1
+        step = flat.count
         if wd != 0:
             if decoupled:
-                torch._foreach_mul_(params, 1 - lr * wd)
+                torch._foreach_mul_(flat.param_views, 1 - lr * wd)
             else:
-                grads = torch._foreach_add(grads, params, alpha=wd)
-        torch._foreach_lerp_(exp_avgs, grads, 1 - beta1)
-        torch._foreach_mul_(exp_avg_sqs, beta2)
-        torch._foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2)
+                grad = grad.add(torch.cat(flat.param_views), alpha=wd)
+        flat.exp_avg.lerp_(grad, 1 - beta1)
+        flat.exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
         bias1, bias2 = 1 - beta1 ** step, 1 - beta2 ** step
-        denom = torch._foreach_sqrt(exp_avg_sqs)
-        torch._foreach_div_(denom, bias2 ** 0.5)
-        torch._foreach_add_(denom, eps)
-        torch._foreach_addcdiv_(params, exp_avgs, denom, -(lr / bias1))
+        denom = flat.exp_avg_sq.sqrt().div_(bias2 ** 0.5).add_(eps)
+        update = (flat.exp_avg * (-(lr / bias1))).div_(denom)  # addcdiv's  value * t1 / t2, in its order
+        torch._foreach_add_(flat.param_views, list(update.split(flat.sizes)))
     return True
 
 
-class _LeanAdam(torch.optim.Adam):
+class _LeanMixin:
+    """``step`` through ``_lean_step`` where it applies; anything that changes the state behind its back drops the
+    flat view of it."""
+
+    _decoupled = False
+
     def step(self, closure=None):
-        if closure is not None or not _lean_step(self, decoupled=False):
-            return super().step(closure)
-        return None
+        if closure is None and _lean_step(self, self._decoupled):
+            return None
+        self.__dict__["_flat_state"] = None  # torch's own step may leave the parameters' step counts unequal
+        return super().step(closure)
+
+    def load_state_dict(self, state_dict):
+        self.__dict__["_flat_state"] = None
+        return super().load_state_dict(state_dict)
+
+    def add_param_group(self, param_group):
+        self.__dict__["_flat_state"] = None
+        return super().add_param_group(param_group)
 
 
-class _LeanAdamW(torch.optim.AdamW):
-    def step(self, closure=None):
-        if closure is not None or not _lean_step(self, decoupled=True):
-            return super().step(closure)
-        return None
+class _LeanAdam(_LeanMixin, torch.optim.Adam):
+    _decoupled = False
+
+
+class _LeanAdamW(_LeanMixin, torch.optim.AdamW):
+    _decoupled = True
 
 
 def _clip_grad_norm(params, max_norm):

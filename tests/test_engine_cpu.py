@@ -236,6 +236,20 @@ def test_lean_optimizer_steps_are_torchs_bit_for_bit():
                 a.param_groups[0]["lr"] = b.param_groups[0]["lr"] = 0.035
             if it == 45:  # a parameter without gradient: torch skips it, and so must we
                 ours[2].grad = theirs[2].grad = None
+            if it == 20:  # a checkpoint round trip: the flat buffers are rebuilt from what load_state_dict put there
+                import copy
+                import io
+
+                blobs = []
+                for opt in (a, b):
+                    buf = io.BytesIO()
+                    torch.save(opt.state_dict(), buf)
+                    buf.seek(0)
+                    blobs.append(torch.load(buf, weights_only=False))
+                a = lean(ours, lr=0.05, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, foreach=True)
+                b = ref(theirs, lr=0.05, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, foreach=True)
+                a.load_state_dict(copy.deepcopy(blobs[1]))  # crosswise: each loads the other's checkpoint
+                b.load_state_dict(copy.deepcopy(blobs[0]))
             a.step()
             b.step()
         for p, q in zip(ours, theirs):
