@@ -24,6 +24,7 @@ import tqdm
 
 from .. import _lib
 from ..backend import GPPlan
+from ..gp.explicit import ExplicitObjective
 from ..gp.lowering import lower
 from ..gp.mll import ExactMarginalLogLikelihood, NotPSDError, predictive_mean
 from ..xr_compat import DataArray
@@ -174,6 +175,11 @@ class MeanShortcut:
 
     params: tuple = ()
 
+    def param_values(self):
+        """Current values of ``params`` without side effects on the device (``params`` itself may be refreshed only
+        by ``residual_and_noise``)."""
+        return self.params
+
     def residual_and_noise(self, plan, target):
         raise NotImplementedError
 
@@ -219,6 +225,7 @@ class PriorSpec:
 class MarginalHIP(BaseModel):
     dtype = torch.float64
     device = "cuda"
+    explicit_host_algebra = True  # closed-form host algebra per iteration where the model allows it (gp/explicit.py)
     _plan_factory = staticmethod(GPPlan)  # tests substitute an oracle-backed double; the product never does
 
     def __init__(self, model_config: dict | None = None):
@@ -432,13 +439,18 @@ class MarginalHIP(BaseModel):
         bar = tqdm.tqdm(range(iterations - first), ncols=100, desc=f"Training {first}->{iterations}")
         best, stale, bad_in_a_row, i = float("inf"), 0, 0, 0
         use_penalty = penalty_callback is not None and penalty_weight > 0.0
+        # the iteration's host algebra in closed form where the model allows it (gp/explicit.py); the penalty term is
+        # an autograd expression, so it keeps the autograd path
+        explicit = None if (use_penalty or not self.explicit_host_algebra) else ExplicitObjective.build(self, mll._priors)
         try:
             for i in bar:
                 self._current_iteration = first + i
                 optimizer_obj.zero_grad(set_to_none=True)
-                spec = self._prior()
                 try:
-                    objective = -mll(spec, self._train_y)
+                    if explicit is not None:
+                        objective = torch.tensor([explicit.evaluate()], dtype=torch.float64)
+                    else:
+                        objective = -mll(self._prior(), self._train_y)
                 except Exception:
                     bad_in_a_row += 1
                     if bad_in_a_row > 10:
@@ -460,7 +472,8 @@ class MarginalHIP(BaseModel):
                             f"Encountered more than 10 consecutive NaN/Inf objectives at iteration {i + 1}")
                     continue
                 bad_in_a_row = 0
-                objective.backward()
+                if explicit is None:
+                    objective.backward()
                 total_norm = _clip_grad_norm(params, 1.0)
                 # the reference scans every p.grad for NaN after clipping (engines/gpytorch.py:387-392); a clipped
                 # gradient holds a NaN exactly when the pre-clip norm is NaN or Inf (Inf * 0 = NaN), so one scalar says it

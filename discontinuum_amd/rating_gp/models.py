@@ -135,6 +135,9 @@ class _PowerLawShortcut(MeanShortcut):
     def params(self):
         return (self.powerlaw.a, self.powerlaw.b, self.powerlaw.c, self.second)
 
+    def param_values(self):
+        return (self.powerlaw.a, self.powerlaw.b, self.powerlaw.c, self.likelihood.second_noise)
+
     def residual_and_noise(self, plan, target):
         pw = self.powerlaw
         pw.b.data.clamp_(1.2, 2.5)

@@ -259,3 +259,57 @@ def test_lean_optimizer_steps_are_torchs_bit_for_bit():
         for k in sb["state"]:
             for name in ("step", "exp_avg", "exp_avg_sq"):
                 assert torch.equal(sa["state"][k][name], sb["state"][k][name]), (k, name)
+
+
+@pytest.mark.parametrize("family", ["loadest", "rating"])
+def test_explicit_host_algebra_matches_autograd(family):
+    """gp/explicit.py (closed-form constraints, priors and chain rule) against the autograd path: same objective, same
+    gradient for every parameter, at the initial point and after training has moved the parameters."""
+    from discontinuum_amd.gp.explicit import ExplicitObjective
+
+    if family == "loadest":
+        cov, tgt = loadest_dataset(60)
+        m = LoadestGP()
+        m.fit(cov, tgt, iterations=1)
+    else:
+        cov, tgt, unc = rating_dataset(50)
+        m = RatingGP()
+        m.fit(cov, tgt, target_unc=unc, iterations=1)
+    m.model.train()
+    m.likelihood.train()
+    for trial in range(3):
+        if trial:  # move every parameter somewhere else
+            with torch.no_grad():
+                for p in m.model.parameters():
+                    p.add_(0.3 * torch.randn(p.shape, dtype=p.dtype))
+        mll = ExactMarginalLogLikelihood(m.likelihood, m.model)
+        explicit = ExplicitObjective.build(m, mll._priors)
+        assert explicit is not None, "the shipped models must take the closed-form path"
+        params = list(m.model.parameters())
+        for p in params:
+            p.grad = None
+        value = explicit.evaluate()
+        got = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        objective = -mll(m._prior(), m._train_y)
+        objective.backward()
+        assert abs(value - objective.item()) <= 1e-12 * max(1.0, abs(objective.item()))
+        for p, g in zip(params, got):
+            assert p.grad is not None and g.shape == p.grad.shape
+            assert torch.allclose(g, p.grad, rtol=1e-10, atol=1e-13), (family, trial, g, p.grad)
+
+
+def test_explicit_host_algebra_declines_what_it_cannot_match():
+    """A prior on something that is not one constrained parameter value keeps the autograd path."""
+    from discontinuum_amd.gp.explicit import ExplicitObjective
+    from discontinuum_amd.gp.priors import NormalPrior
+
+    cov, tgt = loadest_dataset(40)
+    m = LoadestGP()
+    m.fit(cov, tgt, iterations=1)
+    scale = m.model.covar_module.kernels[0]
+    scale.register_prior("odd_prior", NormalPrior(0.0, 1.0), lambda mod: mod.outputscale * 2.0)
+    mll = ExactMarginalLogLikelihood(m.likelihood, m.model)
+    assert ExplicitObjective.build(m, mll._priors) is None
+    m.fit(cov, tgt, iterations=3)  # and training still works, through autograd
