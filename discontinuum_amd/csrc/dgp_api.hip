@@ -309,32 +309,68 @@ static void tick(dgp_plan* p, int stage, int stop, hipStream_t s) {
   if (p->timing && p->tev) (void)hipEventRecord(p->tev[2 * stage + stop], s);
 }
 
+// The tail of a fit step in ONE launch: dnoise_i = 1/2 (S_ii - alpha_i^2), dr = alpha, and the result row -- NLL,
+// log-determinant, quadratic form, pivot status, and the reductions of dNLL/dr (= alpha) and dNLL/dnoise that a host-side
+// mean / noise model needs for its gradients (sum dr, sum dr w0, sum dr w1, sum dnoise), so that the host never reduces
+// device vectors.  Every workgroup handles 256 observations and leaves its partial sums in `part`; the last one to
+// finish (ticket counter info[1], reset for the next step) adds them up in workgroup order and writes the row: the
+// result does not depend on scheduling.  zero_grad (dgp_factorize): one workgroup, scalars only.
 template <typename T>
-__global__ void assemble_kernel(const T* scal, const int* info, long n, int ntheta, int zero_grad, T* out, long bs,
-                                long ibs, const int* ns, const T* alpha, const T* w, const T* dnoise, long nfull) {
+__global__ __launch_bounds__(256) void finish_kernel(const T* scal, int* info, long n, int ntheta, int zero_grad, T* out,
+                                                     long bs, long ibs, const int* ns, const T* alpha, const T* w, const T* S,
+                                                     long N, T* dnoise, T* dr, T* part) {
+  const long nfull = n;
   n = site_n(ns, (int)n);
   scal = site(scal, bs);
   info = site(info, ibs);
   alpha = site(alpha, bs);
+  S = site(S, bs);
+  part = site(part, bs);
   if (dnoise) dnoise = site(dnoise, nfull);
+  if (dr) dr = site(dr, nfull);
   if (w) w = site(w, 2 * nfull);  // [site][2][n]
   out = site(out, (long)DGP_OUT_LEN);
-  const int t = threadIdx.x;
-  // reductions of dNLL/dr (= alpha) and dNLL/dnoise that a parametric prior mean / a learned noise term need for
-  // their gradients, so that the host never reduces device vectors: sum dr, sum dr w0, sum dr w1, sum dnoise
-  T red[4] = {T(0), T(0), T(0), T(0)};
-  if (!zero_grad)
-    for (long i = t; i < n; i += 64) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  __shared__ T red[4][4];
+  __shared__ int last;
+  T v[4] = {T(0), T(0), T(0), T(0)};
+  if (!zero_grad) {
+    const long i = (long)blockIdx.x * 256 + t;
+    if (i < nfull) {
       const T a = alpha[i];
-      red[0] += a;
-      if (w) {
-        red[1] += a * w[i];
-        red[2] += a * w[nfull + i];
+      const T dn = i < n ? T(0.5) * (S[i * N + i] - a * a) : T(0);
+      if (dnoise) dnoise[i] = dn;
+      if (dr) dr[i] = a;
+      if (i < n) {
+        v[0] = a;
+        if (w) {
+          v[1] = a * w[i];
+          v[2] = a * w[nfull + i];
+        }
+        v[3] = dn;
       }
-      if (dnoise) red[3] += dnoise[i];
     }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) red[q] = __shfl(wave_sum(red[q]), 0, 64);  // lane 0 holds the total: hand it on
+    for (int q = 0; q < 4; ++q) {
+      const T sum = wave_sum(v[q]);
+      if (lane == 0) red[wv][q] = sum;
+    }
+    __syncthreads();
+    if (t < 4) part[(long)blockIdx.x * 4 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    __threadfence();
+  }
+  if (t == 0) last = (gridDim.x == 1) || (atomicAdd(&info[1], 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (t == 0) info[1] = 0;
+  if (t < 4) {
+    T total = T(0);
+    if (!zero_grad)
+      for (unsigned g = 0; g < gridDim.x; ++g) total += ((const volatile T*)part)[(long)g * 4 + t];  // other workgroups' stores
+    red[0][t] = total;
+  }
+  __syncthreads();
   if (t == 0) {
     const T logdet = scal[0], quad = scal[1];
     out[DGP_OUT_NLL] = T(0.5) * quad + T(0.5) * logdet + T(0.5 * 1.83787706640934548356) * (T)n;
@@ -343,7 +379,7 @@ __global__ void assemble_kernel(const T* scal, const int* info, long n, int nthe
     out[DGP_OUT_INFO] = (T)info[0];
   }
   if (zero_grad && t >= DGP_OUT_DTHETA && t < DGP_OUT_LEN) out[t] = T(0);
-  if (!zero_grad && t >= DGP_OUT_DTHETA + ntheta && t < DGP_OUT_LEN) out[t] = t >= DGP_OUT_SUM_DR ? red[t - DGP_OUT_SUM_DR] : T(0);
+  if (!zero_grad && t >= DGP_OUT_DTHETA + ntheta && t < DGP_OUT_LEN) out[t] = t >= DGP_OUT_SUM_DR ? red[0][t - DGP_OUT_SUM_DR] : T(0);
 }
 
 template <typename T>
@@ -469,14 +505,12 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
     tick(p, TS_GRAD, 1, s);
     p->timed_valid = p->timing && p->tev;
     p->have_inverse = 1;
-    if (dnoise && (rc = finish<T>((const T*)p->S, (const T*)p->alpha, p->N, (int)p->n, (T*)dnoise, s, bt))) return rc;
-    if (dr)
-      copy_n_kernel<T><<<dim3((unsigned)((p->n + 255) / 256), 1, (unsigned)bt.B), 256, 0, s>>>((const T*)p->alpha, p->n,
-                                                                                           (T*)dr, bt.ws);
   }
-  assemble_kernel<T><<<dim3(1, 1, (unsigned)bt.B), 64, 0, s>>>((const T*)p->scal, p->info, (long)p->n, p->ntheta, !with_grad,
-                                                             (T*)out, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int), bt.ns, (const T*)p->alpha,
-                                                             (const T*)(with_grad ? p->dr_w : nullptr), (const T*)(with_grad ? dnoise : nullptr), (long)p->n);
+  const unsigned nwg = with_grad ? (unsigned)((p->n + 255) / 256) : 1u;
+  finish_kernel<T><<<dim3(nwg, 1, (unsigned)bt.B), 256, 0, s>>>(
+      (const T*)p->scal, p->info, (long)p->n, p->ntheta, !with_grad, (T*)out, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int), bt.ns,
+      (const T*)p->alpha, (const T*)(with_grad ? p->dr_w : nullptr), (const T*)p->S, p->N, (T*)(with_grad ? dnoise : nullptr),
+      (T*)(with_grad ? dr : nullptr), (T*)p->spart);
   p->have_factor = 1;
   return (int)hipGetLastError();
 }

@@ -142,20 +142,9 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, lon
   G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] = -v; });
 }
 
-template <typename T>
-__global__ void zero1_kernel(T* p, int* info, long bs, long ibs) {
-  p = site(p, bs);
-  info = site(info, ibs);
-  if (threadIdx.x == 0) {
-    p[0] = T(0);
-    info[0] = 0;
-  }
-  for (int i = threadIdx.x; i < 2 * EARLY_CTR_PAIRS; i += blockDim.x) info[EARLY_CTR0 + i] = 0;  // early-launch queues
-}
-
 // launch the LDS-resident diagonal-block kernel (needs > 64 KB of dynamic LDS: opt in once per type)
 template <typename T>
-static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hipStream_t s, Batch bt) {
+static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hipStream_t s, Batch bt, bool init = false) {
   static bool configured = false;
   const size_t bytes = potrf_diag_fast_smem<T>();
   if (!configured) {
@@ -164,7 +153,8 @@ static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hi
     configured = true;
   }
   potrf_diag_fast_kernel<T><<<dim3(1, 1, (unsigned)bt.B), 256, bytes, s>>>(A, N, k0, Tinv, logdet, info, bt.ws,
-                                                                           bt.ws * (long)sizeof(T) / (long)sizeof(int));
+                                                                           bt.ws * (long)sizeof(T) / (long)sizeof(int),
+                                                                           init ? 1 : 0, POTRF_INFO_INTS);
 }
 
 template <typename T>
@@ -185,12 +175,11 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
   int ns = 0;
   double flop = 0.0;
   const unsigned Bz = (unsigned)bt.B;
-  zero1_kernel<T><<<dim3(1, 1, Bz), 64, 0, s>>>(logdet, info, bt.ws, bt.ws * (long)sizeof(T) / (long)sizeof(int));
   auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
   const double tile_flop = 2.0 * NB * NB * NB;
   if (!lookahead || nbk < 4 || s2 == nullptr || ev == nullptr) {
     for (int k = 0; k < nbk; ++k) {
-      launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt);
+      launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt, k == 0);
       if (k + 1 < nbk) {
         trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, Bz), 256, 0, s>>>(A, Tinv, N, k, bt.ws);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
@@ -247,7 +236,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
       for (int h = 0; h < ncol; ++h) {
         const int k = k0 + h;
         if (h >= 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2, Bz), 256, 0, s>>>(A, N, k0, h, k, nbk, 1, bt.ws);
-        launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt);
+        launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt, k == 0);
         if (k + 1 < nbk) trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, Bz), 256, 0, s>>>(A, Tinv, N, k, bt.ws);
         checkpoint(k + 1);
       }
@@ -676,18 +665,21 @@ __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ Tm, l
   if (lane == 0) z[i] = acc;
 }
 
-// partial[c][j] = sum_{i in chunk c, i >= blockrow(j)} T[i][j] z_i  (64 columns per workgroup)
+// partial[c][j] = sum_{i in chunk c, i >= blockrow(j)} T[i][j] z_i  (64 columns per workgroup).  Row chunks of 512 for
+// large matrices; 128 below N = 2048, where the 4 x N/128 dependent loads per thread of a 512-chunk are the whole
+// latency of the kernel (N = 384: 19 -> 6 us)
 #define DGP_TRMV_CHUNK 512
+static inline int trmv_chunk(long N) { return N < 2048 ? 128 : DGP_TRMV_CHUNK; }
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_t_kernel(const T* __restrict__ Tm, long ld, const T* __restrict__ z,
-                                                     T* __restrict__ partial, long bs) {
+                                                     T* __restrict__ partial, long bs, int chunk) {
   Tm = site(Tm, bs);
   z = site(z, bs);
   partial = site(partial, bs);
   __shared__ T red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long j = (long)blockIdx.x * 64 + tx;
-  const long r0 = (long)blockIdx.y * DGP_TRMV_CHUNK, r1 = min(r0 + (long)DGP_TRMV_CHUNK, ld);
+  const long r0 = (long)blockIdx.y * chunk, r1 = min(r0 + (long)chunk, ld);
   const long rstart = max(r0, ((long)blockIdx.x * 64 / NB) * NB);
   T acc = T(0);
   for (long i = rstart + ty; i < r1; i += 4) acc += Tm[i * ld + j] * z[i];
@@ -696,33 +688,34 @@ __global__ __launch_bounds__(256) void trmv_t_kernel(const T* __restrict__ Tm, l
   if (ty == 0) partial[(long)blockIdx.y * ld + j] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
+// alpha[j] = sum over the row chunks; the LAST workgroup instead computes quad = z^T z (one launch less)
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_t_reduce_kernel(const T* __restrict__ partial, long N, int nchunks,
-                                                            T* __restrict__ alpha, long bs) {
+                                                            T* __restrict__ alpha, long bs, int chunk,
+                                                            const T* __restrict__ z, T* __restrict__ quad) {
+  if (blockIdx.x == gridDim.x - 1) {
+    z = site(z, bs);
+    quad = site(quad, bs);
+    __shared__ T red[256];
+    T acc = T(0);
+    for (long i = threadIdx.x; i < N; i += 256) acc += z[i] * z[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) quad[0] = red[0];
+    return;
+  }
   partial = site(partial, bs);
   alpha = site(alpha, bs);
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= N) return;
   T acc = T(0);
-  const int c0 = (int)((j / NB) * NB / DGP_TRMV_CHUNK);
+  const int c0 = (int)((j / NB) * NB / chunk);
   for (int c = c0; c < nchunks; ++c) acc += partial[(long)c * N + j];
   alpha[j] = acc;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ z, long N, T* __restrict__ out, long bs) {
-  z = site(z, bs);
-  out = site(out, bs);
-  __shared__ T red[256];
-  T acc = T(0);
-  for (long i = threadIdx.x; i < N; i += 256) acc += z[i] * z[i];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = red[0];
 }
 
 // beta = S g for a symmetric matrix stored in its lower triangle (diagonal tiles hold both halves):
@@ -775,17 +768,17 @@ int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T
   return (int)hipGetLastError();
 }
 
-long solve_partials(long N) { return (N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK * N; }
+long solve_partials(long N) { return (N + trmv_chunk(N) - 1) / trmv_chunk(N) * N; }
 
 template <typename T>
 int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T* quad, hipStream_t s, Batch bt) {
   const unsigned Bz = (unsigned)bt.B;
   trmv_n_kernel<T><<<dim3((unsigned)(N / 4), 1, Bz), 256, 0, s>>>(Tm, N, r, n, z, bt.ws, bt.ns);
-  sumsq_kernel<T><<<dim3(1, 1, Bz), 256, 0, s>>>(z, N, quad, bt.ws);
-  const int nchunks = (int)((N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK);
+  const int chunk = trmv_chunk(N), nchunks = (int)((N + chunk - 1) / chunk);
   dim3 grid((unsigned)(N / 64), (unsigned)nchunks, Bz);
-  trmv_t_kernel<T><<<grid, 256, 0, s>>>(Tm, N, z, partials, bt.ws);
-  trmv_t_reduce_kernel<T><<<dim3((unsigned)((N + 255) / 256), 1, Bz), 256, 0, s>>>(partials, N, nchunks, alpha, bt.ws);
+  trmv_t_kernel<T><<<grid, 256, 0, s>>>(Tm, N, z, partials, bt.ws, chunk);
+  trmv_t_reduce_kernel<T><<<dim3((unsigned)((N + 255) / 256) + 1, 1, Bz), 256, 0, s>>>(partials, N, nchunks, alpha, bt.ws, chunk,
+                                                                                   z, quad);
   return (int)hipGetLastError();
 }
 

@@ -152,11 +152,16 @@ __device__ long long dgp_diag_prof[16];
 template <typename T>
 __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A, long ld, long k0,
                                                               T* __restrict__ Tinv, T* __restrict__ logdet,
-                                                              int* __restrict__ info, long bs, long ibs) {
+                                                              int* __restrict__ info, long bs, long ibs, int init,
+                                                              int ninit) {
   A = site(A, bs);
   Tinv = site(Tinv, bs);
   logdet = site(logdet, bs);
   info = site(info, ibs);
+  // the first diagonal block of a factorisation also resets its status words: info[0] (first bad pivot), the finish
+  // kernel's ticket and the early-launch queue counters -- nothing else runs on this matrix yet
+  if (init)
+    for (int i = threadIdx.x; i < ninit; i += 256) info[i] = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char dg_smem[];
   using acc_t = typename Mfma<T>::acc_t;
   // LDS budget (fp64): 36 + 8 sub-blocks of 16x17 + 128 pivots = 96.7 KB.  It has to stay well below
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
     __syncthreads();
   }
   if (t == 0) {
-    logdet[0] += red[0];  // diag kernels of one factorisation run in stream order
+    logdet[0] = init ? red[0] : logdet[0] + red[0];  // diag kernels of one factorisation run in stream order
     if (bad < 128) atomicCAS(info, 0, (int)(k0 + bad + 1));
   }
   DGP_DIAG_STAMP(7)

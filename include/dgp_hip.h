@@ -45,7 +45,7 @@ extern "C" {
 #define DGP_OUT_DTHETA 4 /* d NLL / d theta_p, p = 0 .. ntheta-1 */
 #define DGP_OUT_SUM_DR 28 /* sum_i d NLL / d r_i (gradient of a constant prior mean is its negative); fit step only */
 #define DGP_OUT_DR_W0 29  /* sum_i d NLL / d r_i * w0[i], and w1 in the next slot: see dgp_plan_set_dr_weights */
-#define DGP_OUT_SUM_DNOISE 31 /* sum_i d NLL / d noise_i (gradient of a homoskedastic noise term); needs dnoise_dev */
+#define DGP_OUT_SUM_DNOISE 31 /* sum_i d NLL / d noise_i (gradient of a homoskedastic noise term); fit step only */
 #define DGP_OUT_LEN 32
 
 /* buffers exposed by dgp_plan_buffer (tests and profiling) */
