@@ -61,6 +61,8 @@ class ExplicitObjective:
         params = list(engine.model.parameters())
         if any(p.dtype != torch.float64 or p.device.type != "cpu" for p in params):
             raise _Unsupported("host parameters must be float64 CPU tensors")
+        if not all(p.requires_grad for p in params):
+            raise _Unsupported("frozen parameters: autograd knows which gradients to skip")
         # constraint of every parameter (None: used as it is)
         constraint = {}
         for mod in engine.model.modules():
