@@ -73,7 +73,7 @@ def _flat_state(opt, params):
     return flat
 
 
-def _lean_step(opt, decoupled):
+def _lean_step(opt, decoupled, flat_grad=None):
     """One Adam / AdamW step with the arithmetic of ``torch.optim.adam._multi_tensor_adam`` (no amsgrad / maximize /
     capturable), element for element, on FLAT views of the state: a dozen scalar-sized host parameters cost torch's
     ``Optimizer.step`` about 200 us, three quarters of it bookkeeping and per-tensor dispatch; this is a dozen vector
@@ -87,16 +87,22 @@ def _lean_step(opt, decoupled):
     params = group["params"]
     if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable"):
         return False
-    for p in params:
-        if p.grad is None or p.grad.is_sparse:
-            return False
+    if flat_grad is None:
+        for p in params:
+            if p.grad is None or p.grad.is_sparse:
+                return False
     with torch.no_grad():
         flat = _flat_state(opt, params)
         if flat is None:
             return False
         beta1, beta2 = group["betas"]
         lr, wd, eps = float(group["lr"]), group["weight_decay"], group["eps"]
-        grad = torch.cat([p.grad.reshape(-1) for p in params])
+        if flat_grad is None:
+            grad = torch.cat([p.grad.reshape(-1) for p in params])
+        elif flat_grad.numel() != flat.exp_avg.numel():
+            return False
+        else:
+            grad = flat_grad  # the caller's gradient of all parameters in group order (never modified here)
         flat.steps += 1
         flat.count += 1
         step = flat.count
@@ -125,6 +131,11 @@ class _LeanMixin:
             return None
         self.__dict__["_flat_state"] = None  # torch's own step may leave the parameters' step counts unequal
         return super().step(closure)
+
+    def step_flat(self, flat_grad):
+        """A step from the gradient of all parameters as ONE flat tensor (group order).  False if the flat state is
+        not available (before torch's first step has created it): the caller then sets ``p.grad`` and calls ``step``."""
+        return _lean_step(self, self._decoupled, flat_grad)
 
     def load_state_dict(self, state_dict):
         self.__dict__["_flat_state"] = None
@@ -448,7 +459,7 @@ class MarginalHIP(BaseModel):
                 optimizer_obj.zero_grad(set_to_none=True)
                 try:
                     if explicit is not None:
-                        objective = torch.tensor([explicit.evaluate()], dtype=torch.float64)
+                        objective = torch.tensor([explicit.evaluate(set_grads=False)], dtype=torch.float64)
                     else:
                         objective = -mll(self._prior(), self._train_y)
                 except Exception:
@@ -472,9 +483,16 @@ class MarginalHIP(BaseModel):
                             f"Encountered more than 10 consecutive NaN/Inf objectives at iteration {i + 1}")
                     continue
                 bad_in_a_row = 0
+                stepped = False
                 if explicit is None:
                     objective.backward()
-                total_norm = _clip_grad_norm(params, 1.0)
+                    total_norm = _clip_grad_norm(params, 1.0)
+                else:  # the gradient of all parameters is one flat array: clip it and step from it directly
+                    total_norm = explicit.clip_flat_grad(1.0)
+                    if math.isfinite(total_norm) and hasattr(optimizer_obj, "step_flat"):
+                        stepped = optimizer_obj.step_flat(torch.from_numpy(explicit.flat_grad))
+                    if not stepped:
+                        explicit.assign_param_grads()
                 # the reference scans every p.grad for NaN after clipping (engines/gpytorch.py:387-392); a clipped
                 # gradient holds a NaN exactly when the pre-clip norm is NaN or Inf (Inf * 0 = NaN), so one scalar says it
                 grads_broken = not math.isfinite(float(total_norm))
@@ -482,7 +500,8 @@ class MarginalHIP(BaseModel):
                     for p in params:
                         if p.grad is not None:
                             p.grad = torch.nan_to_num(p.grad, nan=0.0, posinf=0.0, neginf=0.0)
-                optimizer_obj.step()
+                if not stepped:
+                    optimizer_obj.step()
                 value = float(objective.item())
                 if scheduler_obj is not None:
                     scheduler_obj.step(value)

@@ -211,9 +211,10 @@ class ExplicitObjective:
                 return
         raise NotPSDError(f"Matrix not positive definite: Cholesky pivot {int(row[_lib.OUT_INFO])} is not positive")
 
-    def evaluate(self):
-        """One objective evaluation: launches the device step, sets ``p.grad`` of every parameter, returns the value
-        (a float).  Same arithmetic as ``-mll(model(train_x), train_y)`` + ``backward()``."""
+    def evaluate(self, set_grads=True):
+        """One objective evaluation: launches the device step, leaves d objective / d raw of all parameters in
+        ``flat_grad`` (and as ``p.grad`` of every parameter unless ``set_grads`` is False), returns the value (a
+        float).  Same arithmetic as ``-mll(model(train_x), train_y)`` + ``backward()``."""
         eng = self.engine
         with torch.no_grad():
             r, noise = self.shortcut.residual_and_noise(eng._plan, eng._train_y)
@@ -226,10 +227,23 @@ class ExplicitObjective:
         gx = -dlp
         np.add.at(gx, self.theta_src, row[_lib.OUT_DTHETA:_lib.OUT_DTHETA + self.ntheta])
         np.add.at(gx, self.shortcut_src, np.asarray([float(v) for v in self.shortcut.grads(row)]))
-        graw = gx * slope / n
-        for k, p in enumerate(self.params):
-            p.grad = torch.from_numpy(graw[self.offsets[k]:self.offsets[k + 1]].reshape(tuple(p.shape)))
+        self.flat_grad = gx * slope / n  # d objective / d raw, all parameters, in ``params`` order
+        if set_grads:
+            self.assign_param_grads()
         return (float(row[_lib.OUT_NLL]) - lp) / n
+
+    def assign_param_grads(self):
+        """``p.grad`` of every parameter as views of the flat gradient of the last ``evaluate``."""
+        for k, p in enumerate(self.params):
+            p.grad = torch.from_numpy(self.flat_grad[self.offsets[k]:self.offsets[k + 1]].reshape(tuple(p.shape)))
+
+    def clip_flat_grad(self, max_norm):
+        """``clip_grad_norm_(params, max_norm)`` on the flat gradient; returns the norm before clipping."""
+        total = float(np.sqrt(np.dot(self.flat_grad, self.flat_grad)))
+        coef = max_norm / (total + 1e-6)
+        if not coef >= 1.0:
+            self.flat_grad *= coef
+        return total
 
 
 class _Unsupported(Exception):

@@ -313,3 +313,24 @@ def test_explicit_host_algebra_declines_what_it_cannot_match():
     mll = ExactMarginalLogLikelihood(m.likelihood, m.model)
     assert ExplicitObjective.build(m, mll._priors) is None
     m.fit(cov, tgt, iterations=3)  # and training still works, through autograd
+
+
+@pytest.mark.parametrize("family", ["loadest", "rating"])
+def test_closed_form_training_follows_the_autograd_trajectory(family, monkeypatch):
+    """A whole fit through the closed-form host algebra (flat gradient, flat clip, flat optimiser step) against the
+    same fit through autograd: the parameters stay together to rounding."""
+    def run(explicit):
+        monkeypatch.setattr(MarginalHIP, "explicit_host_algebra", explicit)
+        torch.manual_seed(123)
+        if family == "loadest":
+            cov, tgt = loadest_dataset(45, seed=4)
+            m = LoadestGP()
+            m.fit(cov, tgt, iterations=25, learning_rate=0.1)
+        else:
+            cov, tgt, unc = rating_dataset(40, seed=4)
+            m = RatingGP()
+            m.fit(cov, tgt, target_unc=unc, iterations=25, learning_rate=0.1)
+        return torch.cat([p.detach().reshape(-1) for p in m.model.parameters()])
+
+    a, b = run(True), run(False)
+    assert torch.allclose(a, b, rtol=1e-8, atol=1e-10), (a - b).abs().max()
