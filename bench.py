@@ -17,14 +17,27 @@ thing as the timed region) is reported next to it (`single_site`).  With N > 1 e
 
 `roofline`     dominant kernel of the step, timed live with HIP events recorded inside the library on the
                stream each kernel is launched on (last step of the timed region).  Algorithmic flops per DESIGN.md.
-`cpu_baseline` the CPU oracle (a dense torch fp64 restatement of the reference's gpytorch math -- gpytorch
-               itself is not installable here) timed on the host cores, rank 0 / N=1 only, bounded sample.
+               `traffic` comes from the committed rocprofv3 --pmc passes and is emitted only when the sources of
+               libdgp_hip.so are the ones those passes were taken on (`source_hash` in the profile JSON).
+`cpu_baseline` the CPU oracle (a dense torch restatement of the reference's gpytorch math -- gpytorch itself is not
+               installable here) on the host cores, rank 0 / N=1 only: median of `--cpu-steps` (5) NLL+gradient steps
+               after one warm-up step at n = 8192 fp64, plus the fp32 figure.
+`configs`      (default single-GPU run only) the other BASELINE.json configurations that fit one GPU, each timed here
+               with its own rooflines: C1 n~300 engine iterations (both models), C3 rating-gp n=16384 d=2 fp32,
+               C4's per-GPU share (64 sites of n=4096 in one batched plan), C5's matrix on one GPU (n=65536 fp32).
+
+`--model rating` runs the headline loop on the rating-gp kernel instead (d = 2); `--config 5` is the torchrun entry
+point of the distributed factorisation + gradient of ONE matrix over all ranks (discontinuum_amd/dist_chol.py).
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
+import hashlib
+import io
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -36,10 +49,13 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # MI355X dense vector/matrix peaks (MI355X_MICROARCH.md; fp64 spec)
 PEAK_HBM_GBS = 8000.0
+LN2 = 0.6931471805599453  # softplus(0): gpytorch's default for every Positive-constrained hyperparameter
+METRIC = "GP fits/sec (NLL+grad step) at n=8192 d=3, 1/2/4/8 MI355X"
 
 
+# ------------------------------------------------------------------------------------------ synthetic sites
 def synth_loadest(n, d, seed):
-    """SURVEY.md section 8d synthetic site: sorted centred decimal years, N(0,1) covariates, standardised target."""
+    """Sorted centred decimal years, N(0,1) covariates, standardised target."""
     rng = np.random.default_rng(seed)
     t = np.sort(rng.uniform(-16.0, 16.0, n))
     cov = rng.standard_normal((n, d - 1))
@@ -48,12 +64,43 @@ def synth_loadest(n, d, seed):
     return np.concatenate([t[:, None], cov], axis=1), y
 
 
-def cpu_baseline(n, d, dtype_name):
-    """Time one NLL + gradient step of the oracle on the host (test infrastructure used as the CPU baseline)."""
+def synth_rating(n, seed):
+    """Time as above, stage = 1 + Beta(2,5), standardised log-discharge-like target, per-observation variances."""
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(-16.0, 16.0, n))
+    s = 1.0 + rng.beta(2.0, 5.0, n)
+    y = 1.6 * np.log(s - 0.5) + 0.2 * np.sin(2 * np.pi * t) * (s < 1.3) + 0.05 * rng.standard_normal(n)
+    y = (y - y.mean()) / y.std()
+    return np.stack([t, s], axis=1), y, rng.uniform(1e-3, 4e-3, n)
+
+
+def site(model, n, d, seed):
+    """-> (X (n,d), r (n,), noise (n,), theta list) of one synthetic site at gpytorch's initial hyperparameters."""
+    if model == "loadest":
+        X, y = synth_loadest(n, d, seed)
+        return X, y, np.full(n, 0.01), [LN2] * (2 * d + 5)
+    X, y, yu = synth_rating(n, seed)
+    # gate location = median stage (inside its Interval constraint), learned noise at its initial value softplus(0)+1e-4
+    return X, y, yu + LN2 + 1e-4, [float(np.median(X[:, 1]))] + [LN2] * 15
+
+
+def source_hash():
+    """sha256 over the sources libdgp_hip.so is built from: profiles are only valid for the tree they were taken on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "discontinuum_amd", "csrc")
+    names = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    for f in names + [os.path.join("..", "..", "include", "dgp_hip.h")]:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(n, d, steps):
+    """The oracle (test infrastructure) as the CPU baseline: median of `steps` NLL+gradient steps after one warm-up."""
     from oracle import gp_oracle as orc
 
     # the GPU box exposes many more hardware threads than the job's CPU share; oversubscribing torch's
-    # intra-op pool makes the dense linear algebra slower, not faster, so cap the pool
+    # intra-op pool makes the dense linear algebra slower, not faster, so the pool is the affinity mask capped at 32
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -61,29 +108,175 @@ def cpu_baseline(n, d, dtype_name):
     cores = max(1, min(avail, 32))
     torch.set_num_threads(cores)
 
-    def one(nn):
+    def timed(nn, dt, reps):
         X, y = synth_loadest(nn, d, 0)
-        X, y = torch.tensor(X), torch.tensor(y)
-        theta = torch.full((orc.loadest_ntheta(d),), 0.6931471805599453, dtype=torch.float64)
-        noise = torch.full((nn,), 0.01, dtype=torch.float64)
-        t0 = time.perf_counter()
-        orc.nll_data_and_grads("loadest", X, y, noise, theta)
-        return time.perf_counter() - t0
+        X, y = torch.tensor(X, dtype=dt), torch.tensor(y, dtype=dt)
+        theta = torch.full((orc.loadest_ntheta(d),), LN2, dtype=dt)
+        noise = torch.full((nn,), 0.01, dtype=dt)
+        out = []
+        for _ in range(reps + 1):  # the first one is the warm-up step
+            t0 = time.perf_counter()
+            orc.nll_data_and_grads("loadest", X, y, noise, theta)
+            out.append(time.perf_counter() - t0)
+        return out[1:]
 
-    # one step at the metric's own n = 8192 costs ~14 s on the GPU box's host share (the bounded sample the
-    # contract asks for); only larger n are sampled at 8192 and scaled by the cubic flop count
-    one(min(512, n))  # warm the thread pool / allocator
     ns = min(n, 8192)
-    t_s = one(ns)
-    fits = 1.0 / t_s
-    scaled = fits * (ns / n) ** 3
-    sample = (f"1 NLL+grad step of oracle/gp_oracle.py (torch CPU fp64 dense, autograd) at n={ns} d={d}, "
-              f"{cores} threads, {t_s:.2f} s")
+    t64 = timed(ns, torch.float64, steps)
+    t32 = timed(ns, torch.float32, max(1, min(steps, 3)))
+    med = statistics.median(t64)
+    scale = (ns / n) ** 3
+    sample = (f"median of {len(t64)} NLL+grad steps of oracle/gp_oracle.py (torch CPU fp64 dense, autograd) after 1 warm-up "
+              f"step at n={ns} d={d}: {med:.2f} s (min {min(t64):.2f}, max {max(t64):.2f}); {cores} torch threads of "
+              f"{avail} in the affinity mask, os.cpu_count()={os.cpu_count()}")
     if ns != n:
         sample += f"; value scaled to n={n} by (n_s/n)^3"
-    return {"value": scaled, "unit": "fits/s", "cores": cores, "kind": "port", "sample": sample}
+    return {"value": scale / med, "unit": "fits/s", "cores": cores, "kind": "port", "sample": sample,
+            "affinity_cores": avail, "steps_s": [round(t, 3) for t in t64],
+            "fp32": {"value": scale / statistics.median(t32), "unit": "fits/s", "steps_s": [round(t, 3) for t in t32],
+                     "note": "same restatement in float32 (the reference's dtype, engines/gpytorch.py:221-222)"}}
 
 
+# ------------------------------------------------------------------------------------------ device-side measurement
+def stage_report(plan, S, dtype_name, level, lib):
+    """Per-stage HIP-event times of the plan's most recent fit step -> stages, dominant kernel, roofline numbers."""
+    N = plan.N
+    ms = plan.get_timing()
+    peak = PEAK_TFLOPS[dtype_name]
+    stages = {
+        "syrk_kernel": {"flops": ms[lib.TIME_SYRK_FLOP], "ms": ms[lib.TIME_SYRK_SUM], "launches": int(ms[lib.TIME_SYRK_N])},
+        "trtri_level_kernel": {"flops": S * N ** 3 / 3.0, "ms": ms[lib.TIME_TRTRI], "launches": None},
+        "lauum_kernel": {"flops": S * N ** 3 / 3.0, "ms": ms[lib.TIME_LAUUM], "launches": 1},
+    }
+    if level == 2:  # most of the inverse ran under the factorisation: its stage time is only the remainder
+        stages["trtri_level_kernel"]["flops"] = None
+    for v in stages.values():
+        v["tflops"] = v["flops"] / (v["ms"] * 1e-3) / 1e12 if (v["flops"] and v["ms"] > 0) else None
+    # the dominant KERNEL: trtri is a stage of a dozen launches of several kernel instantiations, none of which
+    # outweighs the single lauum launch or the bulk syrk launches (profiles/*_kernel_stats.csv)
+    dom = max(("syrk_kernel", "lauum_kernel"), key=lambda k: stages[k]["ms"])
+    esz = 8 if dtype_name == "f64" else 4
+    tri_bytes = N * (N + 64) / 2 * esz * S  # lower-triangle 64 x 64 tiles of all sites of the launch
+    gram_bytes = tri_bytes + plan.n * plan.d * esz * S
+    hbm = lambda b, t: b / (t * 1e-3) / 1e9 if t > 0 else None  # noqa: E731
+    return {
+        "dominant": dom, "achieved": stages[dom]["tflops"], "peak": peak,
+        "frac": stages[dom]["tflops"] / peak if stages[dom]["tflops"] else None,
+        "launches": stages[dom]["launches"], "ms": stages[dom]["ms"],
+        "stages_tflops": {k: v["tflops"] for k, v in stages.items()},
+        "stages_ms": {"gram": ms[lib.TIME_GRAM], "potrf_wall": ms[lib.TIME_POTRF], "syrk_sum": ms[lib.TIME_SYRK_SUM],
+                      "trtri": ms[lib.TIME_TRTRI], "lauum": ms[lib.TIME_LAUUM], "solve": ms[lib.TIME_SOLVE],
+                      "grad": ms[lib.TIME_GRAD]},
+        "potrf_stage_tflops": S * N ** 3 / 3.0 / (ms[lib.TIME_POTRF] * 1e-3) / 1e12 if ms[lib.TIME_POTRF] > 0 else None,
+        "gram_hbm": {"bound": "hbm", "achieved": hbm(gram_bytes, ms[lib.TIME_GRAM]), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "bytes": gram_bytes, "kernel": "gram_sym_kernel (writes the lower-triangle tiles)"},
+        "gram_grad_hbm": {"bound": "hbm", "achieved": hbm(tri_bytes, ms[lib.TIME_GRAD]), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "bytes": tri_bytes, "kernel": "gram_grad_kernel + reduction (reads K^^-1 once)"},
+    }
+
+
+def make_plan(model, n, d, dt, dev, S, level, seed0=0):
+    """A (batched) plan with S synthetic sites resident in HBM -> (plan, theta, r, noise) ready for fit_step."""
+    from discontinuum_amd.backend import GPPlan
+
+    Xs, rs, nz, th = [], [], [], []
+    for sidx in range(S):
+        X, r, noise, theta = site(model, n, d, seed0 + sidx)
+        Xs.append(torch.tensor(X, dtype=dt))
+        rs.append(torch.tensor(r, dtype=dt))
+        nz.append(torch.tensor(noise, dtype=dt))
+        th += theta
+    plan = GPPlan(model, n, d, dtype=dt, device=dev, lookahead=level, batch=S)
+    if S > 1:
+        plan.set_inputs(torch.stack(Xs).to(dev).contiguous())
+        return plan, th, torch.stack(rs).to(dev).contiguous(), torch.stack(nz).to(dev).contiguous()
+    plan.set_inputs(Xs[0].to(dev).contiguous())
+    return plan, th, rs[0].to(dev).contiguous(), nz[0].to(dev).contiguous()
+
+
+def time_config(name, model, n, d, dtype_name, S, steps, warmup, dev, lib, level=None):
+    """One BASELINE configuration on this GPU: `steps` timed fit steps of S sites in one plan."""
+    dt = torch.float64 if dtype_name == "f64" else torch.float32
+    level = (1 if S > 1 else 2) if level is None else level
+    plan, th, r, noise = make_plan(model, n, d, dt, dev, S, level)
+    plan.set_timing(True)
+    for _ in range(warmup):
+        out = plan.fit_step(th, r, noise)[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = plan.fit_step(th, r, noise)[0]
+    torch.cuda.synchronize()
+    dtm = (time.perf_counter() - t0) / steps
+    host = out.reshape(S, -1).cpu().double()
+    ok = bool((host[:, lib.OUT_INFO] == 0).all()) and bool(torch.isfinite(host[:, lib.OUT_NLL]).all())
+    rep = stage_report(plan, S, dtype_name, level, lib)
+    N = plan.N
+    res = {"workload": name, "model": model, "n": n, "d": d, "dtype": dtype_name, "sites_in_plan": S, "steps": steps,
+           "ms_per_step": dtm * 1e3, "fits_per_s": S / dtm, "tflops": S * float(N) ** 3 / dtm / 1e12,
+           "frac_of_peak": S * float(N) ** 3 / dtm / 1e12 / PEAK_TFLOPS[dtype_name], "ok": ok,
+           "nll_site0": float(host[0, lib.OUT_NLL]), "hbm_gib": plan._ws.numel() / 2 ** 30, "lookahead": level,
+           "roofline": {"bound": "mfma", "kernel": rep["dominant"], "achieved": rep["achieved"], "peak": rep["peak"],
+                        "unit": "TFLOP/s", "frac": rep["frac"], "ms_per_step": rep["ms"]},
+           "stages_ms": rep["stages_ms"], "stages_tflops": rep["stages_tflops"],
+           "gram_hbm_gbs": rep["gram_hbm"]["achieved"], "gram_grad_hbm_gbs": rep["gram_grad_hbm"]["achieved"]}
+    del plan
+    torch.cuda.empty_cache()
+    return res
+
+
+def engine_iteration(family, n, iters):
+    """BASELINE config 1 through the engine surface: ms per training iteration of `model.fit` (host loop + device step)."""
+    from discontinuum_amd.xr_compat import DataArray, Dataset
+
+    rng = np.random.default_rng(0)
+    if family == "loadest":
+        from discontinuum_amd.loadest_gp import LoadestGP as Model
+
+        t = (np.datetime64("1990-01-01") + np.sort(rng.choice(365 * 30, n, replace=False)).astype("timedelta64[D]")).astype("datetime64[ns]")
+        flow = np.exp(rng.standard_normal(n)) * 10
+        conc = np.exp(0.3 * np.log(flow) + 0.2 * rng.standard_normal(n))
+        args = (Dataset({"flow": ("time", flow)}, coords={"time": t}), DataArray(conc, dims=("time",), coords={"time": t}, name="c"))
+        kw = {}
+    else:
+        from discontinuum_amd.rating_gp import RatingGP as Model
+
+        t = (np.datetime64("2005-01-01") + np.sort(rng.choice(365 * 15, n, replace=False)).astype("timedelta64[D]")).astype("datetime64[ns]")
+        stage = 1.0 + 3.0 * rng.beta(2, 5, n)
+        q = np.exp(1.6 * np.log(stage) + 0.05 * rng.standard_normal(n))
+        args = (Dataset({"stage": ("time", stage)}, coords={"time": t}), DataArray(q, dims=("time",), coords={"time": t}, name="q"))
+        kw = {"target_unc": DataArray(np.full(n, 1.05), dims=("time",), coords={"time": t}, name="q_unc")}
+    m = Model()
+    with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):  # the progress bar
+        m.fit(*args, iterations=5, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.fit(*args, iterations=iters, **kw)
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t0) / iters
+        t1 = time.perf_counter()
+        m.predict(args[0])
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - t1
+    return {"workload": f"{family}-gp demo-size site, n={n} d=2 fp64, `model.fit` through the engine surface", "n": n,
+            "iterations": iters, "ms_per_iteration": dtm * 1e3, "fits_per_s": 1.0 / dtm, "predict_ms": tp * 1e3}
+
+
+def run_configs(dev, lib, quick):
+    """The BASELINE.json configurations other than the headline that fit one GPU, timed in this run."""
+    out = {}
+    out["C1_loadest_n300_engine"] = engine_iteration("loadest", 300, 50 if quick else 200)
+    out["C1_rating_n300_engine"] = engine_iteration("rating", 300, 50 if quick else 200)
+    out["C3_rating_n16384_f32"] = time_config("rating-gp kernel, n=16384 d=2 fp32 exact GP, one site", "rating", 16384, 2,
+                                              "f32", 1, 3 if quick else 8, 2, dev, lib)
+    out["C4_share_64x4096_f64"] = time_config("64 independent loadest sites of n=4096 d=3 fp64 in one batched plan "
+                                              "(BASELINE config 4's per-GPU share of 512 sites / 8 GPUs)", "loadest",
+                                              4096, 3, "f64", 64, 3 if quick else 8, 2, dev, lib)
+    out["C5_matrix_n65536_f32_one_gpu"] = time_config("single n=65536 d=3 fp32 matrix, whole fit step (factor + inverse + "
+                                                      "gradient) on ONE GPU", "loadest", 65536, 3, "f32", 1, 2, 1, dev, lib)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,17 +284,26 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", "--size", dest="n", type=int, default=8192,
                     help="observations per site (--size: torch.distributed.run rejects --n as ambiguous with its own options)")
-    ap.add_argument("--d", type=int, default=3)
+    ap.add_argument("--d", type=int, default=None, help="design-matrix columns (default 3 for loadest, 2 for rating)")
+    ap.add_argument("--model", choices=["loadest", "rating"], default="loadest")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed oracle steps of the CPU baseline (after one warm-up)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (C1, C3, C4 share, C5 on one GPU)")
+    ap.add_argument("--quick-configs", action="store_true", help="fewer steps per config (tests)")
     ap.add_argument("--no-lookahead", action="store_true")
     ap.add_argument("--sites-per-gpu", type=int, default=32,
                     help="independent sites carried in lockstep by one batched plan per GPU (1.5 GiB of HBM each at "
                          "n = 8192 fp64; 8 -> 104.5, 16 -> 106.7, 32 -> 107.6 fits/s)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5],
+                    help="2: the headline loop (default); 5: ONE n x n matrix factored and differentiated across all "
+                         "ranks (dist_chol.distributed_fit_step; --size 65536 --dtype f32 is BASELINE config 5)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the per-kernel timing loop of the roofline object (the command profiled with "
                          "rocprofv3 --kernel-trace --stats for profiles/)")
     args = ap.parse_args()
+    model = args.model
+    d = args.d if args.d is not None else (3 if model == "loadest" else 2)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,39 +332,29 @@ def main():
     from discontinuum_amd.backend import GPPlan
     from discontinuum_amd.sites import gather_site_results
 
-    dt = torch.float64 if args.dtype == "f64" else torch.float32
-    n, d, S = args.n, args.d, max(1, args.sites_per_gpu)
-    ntheta = 2 * d + 5
-    theta = [0.6931471805599453] * ntheta  # gpytorch defaults: softplus(0)
-    noise = torch.full((n,), 0.01, dtype=dt, device=dev)
-    # S independent sites per rank carried by ONE batched plan: every kernel of the fit step is launched once for
-    # all S sites (gridDim.z = S), so the sequential panel chain and the launch rate are amortised over them.
-    # The single-site plan (latency, roofline) uses the default level 2 (early inverse on a third stream).
-    Xs, ys = [], []
-    for sidx in range(S):
-        X, y = synth_loadest(n, d, seed=rank * S + sidx)
-        Xs.append(torch.tensor(X, dtype=dt, device=dev))
-        ys.append(torch.tensor(y, dtype=dt, device=dev).contiguous())
-    level = 0 if args.no_lookahead else (1 if S > 1 else 2)
-    plan = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=0 if args.no_lookahead else 2)
-    plan.set_inputs(Xs[0].contiguous())
-    if S > 1:
-        bplan = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=level, batch=S)
-        bplan.set_inputs(torch.stack(Xs).contiguous())
-        ball = torch.stack(ys).contiguous()
-        bnoise = noise.repeat(S, 1).contiguous()
-        btheta = theta * S
-    else:
-        bplan, ball, bnoise, btheta = plan, ys[0], noise, theta
-
-    def batch_step():
-        out = bplan.fit_step(btheta, ball, bnoise)[0]
-        return list(out) if S > 1 else [out]
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.config == 5:
+        return run_config5(args, model, d, dev, world, rank, dist, barrier, _lib)
+
+    dt = torch.float64 if args.dtype == "f64" else torch.float32
+    n, S = args.n, max(1, args.sites_per_gpu)
+    # S independent sites per rank carried by ONE batched plan: every kernel of the fit step is launched once for
+    # all S sites (gridDim.z = S), so the sequential panel chain and the launch rate are amortised over them.
+    # The single-site plan (latency) uses the default level 2 (early inverse on a third stream).
+    level = 0 if args.no_lookahead else (1 if S > 1 else 2)
+    bplan, btheta, ball, bnoise = make_plan(model, n, d, dt, dev, S, level, seed0=rank * S)
+    if S > 1:
+        plan, theta, y0, noise0 = make_plan(model, n, d, dt, dev, 1, 0 if args.no_lookahead else 2, seed0=rank * S)
+    else:
+        plan, theta, y0, noise0 = bplan, btheta, ball, bnoise
+
+    def batch_step():
+        out = bplan.fit_step(btheta, ball, bnoise)[0]
+        return list(out) if S > 1 else [out]
 
     bplan.set_timing(True)  # HIP events around every bulk launch, on the stream it runs on (the roofline object)
     if args.roofline_only:
@@ -173,7 +365,8 @@ def main():
         print(json.dumps({"roofline_only": True, "kernel": "syrk_kernel", "launches": int(ms[_lib.TIME_SYRK_N]),
                           "ms_per_step": ms[_lib.TIME_SYRK_SUM],
                           "avg_launch_us": 1e3 * ms[_lib.TIME_SYRK_SUM] / max(1, int(ms[_lib.TIME_SYRK_N])),
-                          "achieved_tflops": ms[_lib.TIME_SYRK_FLOP] / (ms[_lib.TIME_SYRK_SUM] * 1e-3) / 1e12}))
+                          "achieved_tflops": ms[_lib.TIME_SYRK_FLOP] / (ms[_lib.TIME_SYRK_SUM] * 1e-3) / 1e12,
+                          "lauum_ms": ms[_lib.TIME_LAUUM], "source_hash": source_hash()}))
         return
     torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -196,66 +389,51 @@ def main():
     assert bool((host[:, _lib.OUT_INFO] == 0).all()) and bool(torch.isfinite(host[:, _lib.OUT_NLL]).all()), "fit step failed"
     assert table.shape[0] == world * S and bool(torch.isfinite(table[:, _lib.OUT_NLL]).all()), "a site failed"
 
-    # ---- single-site loop on rank 0: latency of one fit alone on the GPU + per-kernel HIP-event timings
+    # ---- single-site loop on rank 0: latency of one fit alone on the GPU
     single_ms = None
     if rank == 0:
         ksingle = max(3, args.steps // 2)
-        plan.fit_step(theta, ys[0], noise)
+        plan.fit_step(theta, y0, noise0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(ksingle):
-            plan.fit_step(theta, ys[0], noise)
+            plan.fit_step(theta, y0, noise0)
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / ksingle * 1e3
 
     if rank == 0:
-        N = plan.N
-        ms = bplan.get_timing()  # last step of the timed region
-        esz = 8 if args.dtype == "f64" else 4
-        peak = PEAK_TFLOPS[args.dtype]
-        f_syrk = ms[_lib.TIME_SYRK_FLOP]  # algorithmic flops of the bulk launches, reported by the library
-        stages = {
-            "syrk_kernel": {"flops": f_syrk, "ms": ms[_lib.TIME_SYRK_SUM], "launches": int(ms[_lib.TIME_SYRK_N])},
-            "trtri_level_kernel": {"flops": S * N ** 3 / 3.0, "ms": ms[_lib.TIME_TRTRI], "launches": None},
-            "lauum_kernel": {"flops": S * N ** 3 / 3.0, "ms": ms[_lib.TIME_LAUUM], "launches": 1},
-        }
-        if level == 2:  # most of the inverse ran under the factorisation: its stage time is only the remainder
-            stages["trtri_level_kernel"]["flops"] = None
-        for v in stages.values():
-            v["tflops"] = v["flops"] / (v["ms"] * 1e-3) / 1e12 if (v["flops"] and v["ms"] > 0) else None
-        # the dominant KERNEL: trtri is a stage of a dozen launches of several kernel instantiations, none of which
-        # outweighs the single lauum launch or the bulk syrk launches (profiles/*_kernel_stats.csv)
-        dom = max(("syrk_kernel", "lauum_kernel"), key=lambda k: stages[k]["ms"])
-        ach = stages[dom]["tflops"]
-        gram_bytes = (N * (N + 64) / 2 * esz + n * d * esz) * S  # lower-triangle 64 x 64 tiles written + inputs read, all sites of the launch
+        N = bplan.N
+        rep = stage_report(bplan, S, args.dtype, level, _lib)  # last step of the timed region
+        dom = rep["dominant"]
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, gfx950 half-count correction applied: scripts/pmc_summary.py); only valid
-        # for the shape those passes were taken at
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_n8192_f64.json")
-        if os.path.exists(pmc_path) and (n, d, args.dtype) == (8192, 3, "f64"):
+        # for the shape AND the source tree those passes were taken on
+        traffic, traffic_from = None, None
+        shash = source_hash()
+        for cand in ("r02_pmc_hbm_n8192_f64.json",):
+            pmc_path = os.path.join(ROOT, "profiles", cand)
+            if not os.path.exists(pmc_path) or (model, n, d, args.dtype) != ("loadest", 8192, 3, "f64"):
+                continue
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("sites_per_launch") == S:  # bytes per launch are those of a launch carrying S sites
+                if pmc.get("sites_per_launch") == S and pmc.get("source_hash") == shash:
                     key = next(k for k in pmc["kernels"] if k.startswith(dom))
                     traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+                    traffic_from = f"profiles/{cand} (commit {pmc.get('commit')}, source_hash {shash})"
             except Exception:  # noqa: BLE001
                 traffic = None
         roofline = {
-            "bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak if ach else None, "traffic": traffic,
-            "launches_per_step": stages[dom]["launches"], "ms_per_step": stages[dom]["ms"],
-            "stages_tflops": {k: v["tflops"] for k, v in stages.items()},
-            "stages_ms": {"gram": ms[_lib.TIME_GRAM], "potrf_wall": ms[_lib.TIME_POTRF], "syrk_sum": ms[_lib.TIME_SYRK_SUM],
-                          "trtri": ms[_lib.TIME_TRTRI], "lauum": ms[_lib.TIME_LAUUM], "solve": ms[_lib.TIME_SOLVE],
-                          "grad": ms[_lib.TIME_GRAD]},
+            "bound": "mfma", "kernel": dom, "achieved": rep["achieved"], "peak": rep["peak"], "unit": "TFLOP/s",
+            "frac": rep["frac"], "traffic": traffic, "traffic_from": traffic_from,
+            "launches_per_step": rep["launches"], "ms_per_step": rep["ms"],
+            "stages_tflops": rep["stages_tflops"], "stages_ms": rep["stages_ms"],
+            "potrf_stage_tflops": rep["potrf_stage_tflops"],
             "fit_flops": float(N) ** 3, "job_tflops": float(N) ** 3 * world * S * args.steps / elapsed / 1e12,
             "measured_in": "the timed region itself (last step): every launch carries %d site(s), lookahead level %d" % (S, level),
-            "gram_hbm": {"bound": "hbm", "achieved": gram_bytes / (ms[_lib.TIME_GRAM] * 1e-3) / 1e9 if ms[_lib.TIME_GRAM] > 0 else None,
-                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes": gram_bytes},
+            "gram_hbm": rep["gram_hbm"], "gram_grad_hbm": rep["gram_grad_hbm"], "source_hash": shash,
         }
         result = {
-            "metric": "GP fits/sec (NLL+grad step) at n=8192 d=3, 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": world * S * args.steps / elapsed,
             "unit": "fits/s",
             "n_gpus": world,
@@ -267,19 +445,65 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"synthetic loadest-gp kernel, n={n} d={d} {args.dtype} exact GP, "
+            "config": {"workload": f"synthetic {model}-gp kernel, n={n} d={d} {args.dtype} exact GP, "
                                    f"{S} independent site(s) per GPU in one batched plan (one step = one fit of each)",
                        "n": n, "d": d, "sites_per_gpu": S, "fits_per_step": world * S,
                        "lookahead": not args.no_lookahead, "nll_site0": float(host[0, _lib.OUT_NLL])},
             "single_site": {"fits_per_s": 1e3 / single_ms, "ms_per_fit": single_ms,
+                            "tflops": float(N) ** 3 / (single_ms * 1e-3) / 1e12,
                             "note": "one site alone on one GPU, steps strictly sequential (a single fit loop)"},
             "roofline": roofline,
         }
+        default_run = (world == 1 and (model, n, d, args.dtype) == ("loadest", 8192, 3, "f64"))
+        del bplan, plan
+        torch.cuda.empty_cache()
+        if default_run and not args.no_configs:
+            result["configs"] = run_configs(dev, _lib, args.quick_configs)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(n, d, args.dtype)
+            result["cpu_baseline"] = cpu_baseline(n, d, max(1, args.cpu_steps))
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_config5(args, model, d, dev, world, rank, dist, barrier, lib):
+    """BASELINE config 5: ONE matrix over all ranks -- distributed factorisation, inverse and gradient
+    (discontinuum_amd/dist_chol.py::distributed_fit_step).  One step = one NLL + gradient evaluation."""
+    from discontinuum_amd import dist_chol
+
+    dt = torch.float64 if args.dtype == "f64" else torch.float32
+    n = args.n
+    X, r, noise, theta = site(model, n, d, 0)
+    ctx = dist_chol.DistributedFit(model, n, d, dtype=dt, device=dev, rank=rank, world=world)
+    ctx.set_inputs(torch.tensor(X, dtype=dt, device=dev).contiguous())
+    rd, nd = torch.tensor(r, dtype=dt, device=dev), torch.tensor(noise, dtype=dt, device=dev)
+    for _ in range(args.warmup):
+        out = ctx.fit_step(theta, rd, nd)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = ctx.fit_step(theta, rd, nd)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        N = ctx.N
+        host = out.cpu().double()
+        print(json.dumps({
+            "metric": METRIC, "value": args.steps / elapsed, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"ONE {model}-gp matrix n={n} d={d} {args.dtype}: block-cyclic distributed Cholesky, "
+                                   f"inverse and gradient over {world} rank(s)", "n": n, "d": d,
+                       "nll": float(host[lib.OUT_NLL]), "info": int(host[lib.OUT_INFO])},
+            "job_tflops": float(N) ** 3 * args.steps / elapsed / 1e12,
+            "per_rank_hbm_gib": ctx.hbm_bytes() / 2 ** 30, "cpu_baseline": None, "roofline": None}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

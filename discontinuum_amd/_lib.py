@@ -59,6 +59,7 @@ SIGNATURES = {
     "dgp_predict_workspace_bytes": (_sz, [_vp, _i64]),
     "dgp_predict": (_i, [_vp, _dp, _vp, _i64, _vp, _sz, _vp, _vp, _vp]),
     "dgp_posterior_cov": (_i, [_vp, _dp, _vp, _i64, _vp, _sz, _vp, _vp, _vp]),
+    "dgp_sample_draws": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "dgp_mean_vjp_workspace_bytes": (_sz, [_vp, _i64]),
     "dgp_predict_mean": (_i, [_vp, _dp, _vp, _i64, _vp, _sz, _vp, _vp]),
     "dgp_mean_vjp": (_i, [_vp, _dp, _vp, _i64, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),

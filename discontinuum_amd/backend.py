@@ -161,72 +161,119 @@ class GPPlan:
         return out
 
     def predict(self, theta, Xs: torch.Tensor, chunk: int = 16384):
-        """Latent posterior (K*^T alpha, diag(K** - K*^T K^^-1 K*)) at Xs (m, d) from the held factorisation."""
-        if not (torch.is_tensor(Xs) and Xs.is_cuda and Xs.dtype == self.dtype and Xs.dim() == 2 and Xs.shape[1] == self.d):
-            raise ValueError(f"Xs must be a (m, {self.d}) {self.dtype} CUDA tensor")
-        th = _theta_array(theta, self.ntheta)
-        m = Xs.shape[0]
-        mean = torch.empty(m, dtype=self.dtype, device=self.device)
-        var = torch.empty(m, dtype=self.dtype, device=self.device)
+        """Latent posterior (K*^T alpha, diag(K** - K*^T K^^-1 K*)) at Xs (m, d) from the held factorisation.
+        Batched plans: Xs (batch, m, d), theta (batch, ntheta) -> mean, var (batch, m); every site predicts at its own
+        points from the factorisation the last ``fit_step`` / ``factorize`` left in its slice of the workspace."""
+        lead = () if self.batch == 1 else (self.batch,)
+        if not (torch.is_tensor(Xs) and Xs.is_cuda and Xs.dtype == self.dtype and Xs.dim() == 2 + len(lead)
+                and Xs.shape[-1] == self.d and tuple(Xs.shape[:-2]) == lead):
+            raise ValueError(f"Xs must be a {lead + ('m', self.d)} {self.dtype} CUDA tensor")
+        th = _theta_array(theta, self.ntheta * self.batch)
+        m = Xs.shape[-2]
+        mean = torch.empty(lead + (m,), dtype=self.dtype, device=self.device)
+        var = torch.empty(lead + (m,), dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
             for lo in range(0, m, chunk):
                 hi = min(lo + chunk, m)
-                xs = Xs[lo:hi].contiguous()
+                whole = lo == 0 and hi == m
+                xs = Xs[..., lo:hi, :].contiguous()
                 need = int(self.lib.dgp_predict_workspace_bytes(self._h, hi - lo))
                 if self._pred_ws is None or self._pred_ws.numel() < need + 256:
                     self._pred_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
                 base = self._pred_ws.data_ptr()
                 base += (-base) % 256
+                # a chunk of a batched prediction is not contiguous inside (batch, m): stage it
+                mo = mean if (whole or not lead) else torch.empty(lead + (hi - lo,), dtype=self.dtype, device=self.device)
+                vo = var if (whole or not lead) else torch.empty_like(mo)
+                mp = mo if (whole or lead) else mean[lo:hi]
+                vp = vo if (whole or lead) else var[lo:hi]
                 _lib.check(
-                    self.lib.dgp_predict(
-                        self._h, th, _ptr(xs), hi - lo, C.c_void_p(base), need, _ptr(mean[lo:hi]), _ptr(var[lo:hi]), _stream()
-                    ),
+                    self.lib.dgp_predict(self._h, th, _ptr(xs), hi - lo, C.c_void_p(base), need, _ptr(mp), _ptr(vp), _stream()),
                     "dgp_predict",
                 )
+                if lead and not whole:
+                    mean[:, lo:hi] = mo
+                    var[:, lo:hi] = vo
         return mean, var
 
-    def posterior_factor(self, theta, Xs: torch.Tensor, jitter: float | None = None):
-        """(K*^T alpha, Cholesky factor of the latent posterior covariance at Xs) for ``sample()``.
-        The m x m covariance K** - V^T V comes from ``dgp_posterior_cov``; its factor from the same
-        blocked HIP potrf as the training matrix (a second plan of order m).  ``jitter`` follows
-        linear_operator's psd_safe_cholesky default for the dtype."""
+    # ------------------------------------------------------------------ sample(): posterior covariance, factor, draws
+    def _jitter_ladder(self):
+        """linear_operator's ``psd_safe_cholesky`` policy: first no jitter at all, then the
+        dtype's default (1e-8 fp64 / 1e-6 fp32), then 10x and 100x that; after that it raises."""
+        base = 1e-8 if self.dtype == torch.float64 else 1e-6
+        return (0.0, base, 10 * base, 100 * base)
+
+    def posterior_cov(self, theta, Xs: torch.Tensor):
+        """(K*^T alpha, latent posterior covariance K** - V^T V) at Xs (m, d): the covariance as an (M, M) tensor,
+        M = padded m, lower triangle valid (diagonal 128-blocks complete), identity pad -- ``dgp_posterior_cov``."""
+        if self.batch != 1:
+            raise ValueError("posterior_cov needs a plain (unbatched) plan")
         th = _theta_array(theta, self.ntheta)
         m = Xs.shape[0]
         M = int(self.lib.dgp_padded_n(m))
-        if jitter is None:
-            jitter = 1e-8 if self.dtype == torch.float64 else 1e-6
         with torch.cuda.device(self.device):
             xs = Xs.contiguous()
             need = int(self.lib.dgp_predict_workspace_bytes(self._h, m))
-            work = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
-            base = work.data_ptr() + (-work.data_ptr()) % 256
+            if self._pred_ws is None or self._pred_ws.numel() < need + 256:
+                self._pred_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            base = self._pred_ws.data_ptr()
+            base += (-base) % 256
             mean = torch.empty(m, dtype=self.dtype, device=self.device)
-            fac = getattr(self, "_fac", None)  # the order-m plan whose potrf factors the covariance; kept between calls
-            if fac is None or fac.n != m:
-                self._fac = None
-                self._fac = fac = GPPlan(self.model, m, self.d, dtype=self.dtype, device=self.device)
-            cov = fac.buffer(_lib.BUF_A)
-            assert cov.shape == (M, M)
+            cov = torch.empty(M, M, dtype=self.dtype, device=self.device)
             _lib.check(
                 self.lib.dgp_posterior_cov(self._h, th, _ptr(xs), m, C.c_void_p(base), need, _ptr(mean), _ptr(cov), _stream()),
                 "dgp_posterior_cov",
             )
-            info = -1
-            for attempt in range(4):  # psd_safe_cholesky-style escalation: jitter, 10x, 100x, 1000x
-                if attempt:
-                    _lib.check(
-                        self.lib.dgp_posterior_cov(self._h, th, _ptr(xs), m, C.c_void_p(base), need, _ptr(mean), _ptr(cov), _stream()),
-                        "dgp_posterior_cov",
-                    )
-                cov.diagonal()[:m].add_(jitter * 10 ** attempt)
+        return mean, cov
+
+    def psd_safe_factor(self, cov: torch.Tensor, m: int):
+        """Lower Cholesky factor of the (M, M) matrix ``cov`` (layout of ``posterior_cov``; left untouched) by the
+        blocked HIP potrf of an order-m plan, with ``psd_safe_cholesky``'s jitter policy: the matrix itself first, then
+        + 1e-8 I, 1e-7 I, 1e-6 I (fp32: 1e-6 .. 1e-4), each attempt restarting from the kept matrix; raises after the
+        last.  -> (Lbuf, jitter): Lbuf is that plan's (M, M) buffer -- zeros above the diagonal inside the diagonal
+        128-blocks, identity pad, blocks above the block diagonal undefined -- valid until the next call."""
+        M = int(self.lib.dgp_padded_n(m))
+        if tuple(cov.shape) != (M, M) or cov.dtype != self.dtype or not cov.is_cuda or not cov.is_contiguous():
+            raise ValueError(f"cov must be a contiguous ({M}, {M}) {self.dtype} CUDA tensor")
+        fac = getattr(self, "_fac", None)  # the order-m plan whose potrf factors the covariance; kept between calls
+        if fac is None or fac.n != m:
+            self._fac = None
+            self._fac = fac = GPPlan(self.model, m, self.d, dtype=self.dtype, device=self.device)
+        Lbuf = fac.buffer(_lib.BUF_A)
+        info = -1
+        with torch.cuda.device(self.device):
+            for jitter in self._jitter_ladder():
+                Lbuf.copy_(cov)
+                if jitter:
+                    Lbuf.diagonal()[:m].add_(jitter)
                 fac.stage_potrf()
                 info = fac.potrf_info()
                 if info == 0:
-                    break
-            if info != 0:
-                raise RuntimeError(f"posterior covariance not positive definite (pivot {info})")
-            L = torch.tril(cov[:m, :m]).clone()
-        return mean, L
+                    return Lbuf, jitter
+        raise RuntimeError(f"posterior covariance not positive definite after jitter {jitter:g} (pivot {info})")
+
+    def posterior_factor(self, theta, Xs: torch.Tensor):
+        """-> (K*^T alpha, Lbuf, jitter): ``posterior_cov`` followed by ``psd_safe_factor``."""
+        mean, cov = self.posterior_cov(theta, Xs)
+        Lbuf, jitter = self.psd_safe_factor(cov, Xs.shape[0])
+        return mean, Lbuf, jitter
+
+    def sample_draws(self, Lbuf: torch.Tensor, m: int, mean, ndraw: int, generator=None):
+        """(ndraw, m) draws mean + L z, z ~ N(0, I), through ``dgp_sample_draws`` (one MFMA launch on the factor as
+        ``psd_safe_factor`` leaves it).  The normals come from torch's generator (plumbing); ``self._last_z`` keeps
+        them for the tests."""
+        M = int(self.lib.dgp_padded_n(m))
+        Q = int(self.lib.dgp_padded_n(ndraw))
+        if tuple(Lbuf.shape) != (M, M) or Lbuf.dtype != self.dtype or not Lbuf.is_contiguous():
+            raise ValueError(f"Lbuf must be the contiguous ({M}, {M}) factor buffer")
+        with torch.cuda.device(self.device):
+            z = torch.randn(M, Q, dtype=self.dtype, device=self.device, generator=generator)
+            out = torch.empty(ndraw, m, dtype=self.dtype, device=self.device)
+            mp = _ptr(mean.contiguous()) if mean is not None else None
+            _lib.check(self.lib.dgp_sample_draws(_DTYPES[self.dtype], _ptr(Lbuf), m, _ptr(z), ndraw, mp, _ptr(out), _stream()),
+                       "dgp_sample_draws")
+        self._last_z = z
+        return out
 
     def _vjp_workspace(self, m):
         need = int(self.lib.dgp_mean_vjp_workspace_bytes(self._h, m))
@@ -237,13 +284,16 @@ class GPPlan:
         return C.c_void_p(base + (-base) % 256), need
 
     def predict_mean(self, theta, Xs: torch.Tensor):
-        """K(X*, X) alpha from the held factorisation (no variance work)."""
-        th = _theta_array(theta, self.ntheta)
-        m = Xs.shape[0]
+        """K(X*, X) alpha from the held factorisation (no variance work).  Batched plans: Xs (batch, m, d) -> (batch, m)."""
+        th = _theta_array(theta, self.ntheta * self.batch)
+        lead = () if self.batch == 1 else (self.batch,)
+        if Xs.dim() != 2 + len(lead) or tuple(Xs.shape[:-2]) != lead or Xs.shape[-1] != self.d:
+            raise ValueError(f"Xs must have shape {lead + ('m', self.d)}")
+        m = Xs.shape[-2]
         with torch.cuda.device(self.device):
             xs = Xs.contiguous()
             work, need = self._vjp_workspace(m)
-            mean = torch.empty(m, dtype=self.dtype, device=self.device)
+            mean = torch.empty(lead + (m,), dtype=self.dtype, device=self.device)
             _lib.check(self.lib.dgp_predict_mean(self._h, th, _ptr(xs), m, work, need, _ptr(mean), _stream()), "dgp_predict_mean")
         return mean
 

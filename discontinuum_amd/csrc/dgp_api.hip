@@ -21,8 +21,50 @@ static int hipfail(hipError_t e, const char* where) {
   return (int)e;
 }
 
+// Small host -> device uploads (site sizes, the hyperparameters of large batches) go through PINNED staging slots that
+// the plan owns: an asynchronous copy from pageable memory is only safe while the runtime happens to stage it before
+// returning.  A slot is reused after the event recorded behind its last copy has completed.
+struct PinnedRing {
+  static constexpr int SLOTS = 4;
+  void* buf[SLOTS];
+  size_t cap[SLOTS];
+  hipEvent_t ev[SLOTS];
+  int busy[SLOTS], have_ev[SLOTS], next;
+  void* acquire(size_t bytes) {
+    const int i = next;
+    if (busy[i]) {
+      (void)hipEventSynchronize(ev[i]);
+      busy[i] = 0;
+    }
+    if (cap[i] < bytes) {
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      buf[i] = nullptr;
+      cap[i] = 0;
+      if (hipHostMalloc(&buf[i], bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+      cap[i] = bytes;
+    }
+    return buf[i];
+  }
+  void commit(hipStream_t s) {  // after the copy out of the slot handed out last has been enqueued on s
+    const int i = next;
+    if (!have_ev[i]) have_ev[i] = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+    if (have_ev[i] && hipEventRecord(ev[i], s) == hipSuccess) busy[i] = 1;
+    else (void)hipStreamSynchronize(s);
+    next = (next + 1) % SLOTS;
+  }
+  void destroy() {
+    for (int i = 0; i < SLOTS; ++i) {
+      if (busy[i]) (void)hipEventSynchronize(ev[i]);
+      if (have_ev[i]) (void)hipEventDestroy(ev[i]);
+      if (buf[i]) (void)hipHostFree(buf[i]);
+    }
+  }
+};
+
 struct dgp_plan {
   int model, dtype, d, ntheta;
+  PinnedRing ring;
+  int* nsite_host;        // host copy of the sites' sizes (B > 1): the inference entry points walk the sites on the host
   int B;                  // sites carried in lockstep (1 = plain plan); site b's buffers sit b * site_bytes further on
   size_t site_bytes;
   void* pre;              // device scratch for the batch's hyperparameters (B > 8), after the last site
@@ -144,6 +186,8 @@ int dgp_plan_destroy(dgp_plan* p) {
   if (p->s3) (void)hipStreamDestroy(p->s3);
   if (p->have_xev)
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(p->xev[i]);
+  p->ring.destroy();
+  delete[] p->nsite_host;
   delete p;
   return 0;
 }
@@ -169,13 +213,13 @@ int dgp_plan_set_site_sizes(dgp_plan* p, const int64_t* sizes, void* stream) {
     if (sizes[0] != p->n) return fail(DGP_E_ARG, "dgp_plan_set_site_sizes: an unbatched plan has the size it was created with");
     return 0;
   }
-  std::vector<int> v((size_t)p->B);
-  for (int b = 0; b < p->B; ++b) {
+  for (int b = 0; b < p->B; ++b)
     if (sizes[b] < 1 || sizes[b] > p->n) return fail(DGP_E_ARG, "dgp_plan_set_site_sizes: sizes must be in 1..n");
-    v[b] = (int)sizes[b];
-  }
-  // pageable source: staged before the call returns
-  hipError_t e = hipMemcpyAsync(p->nsite, v.data(), sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice, (hipStream_t)stream);
+  int* v = (int*)p->ring.acquire(sizeof(int) * (size_t)p->B);
+  if (!v) return fail(DGP_E_ARG, "dgp_plan_set_site_sizes: out of pinned host memory");
+  for (int b = 0; b < p->B; ++b) p->nsite_host[b] = v[b] = (int)sizes[b];
+  hipError_t e = hipMemcpyAsync(p->nsite, v, sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice, (hipStream_t)stream);
+  p->ring.commit((hipStream_t)stream);
   if (e != hipSuccess) return hipfail(e, "dgp_plan_set_site_sizes");
   p->have_factor = 0;
   return 0;
@@ -211,8 +255,11 @@ int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   p->dr_w = nullptr;
   if (p->B > 1) {  // every site starts at the full size n
     p->nsite = (int*)(p->ws + L.total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)));
-    std::vector<int> full((size_t)p->B, (int)p->n);
-    hipError_t e = hipMemcpy(p->nsite, full.data(), sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice);
+    delete[] p->nsite_host;
+    p->nsite_host = new (std::nothrow) int[(size_t)p->B];
+    if (!p->nsite_host) return fail(DGP_E_ARG, "dgp_plan_set_workspace: out of host memory");
+    for (int b = 0; b < p->B; ++b) p->nsite_host[b] = (int)p->n;
+    hipError_t e = hipMemcpy(p->nsite, p->nsite_host, sizeof(int) * (size_t)p->B, hipMemcpyHostToDevice);  // blocking
     if (e != hipSuccess) return hipfail(e, "dgp_plan_set_workspace: hipMemcpy");
   }
   p->have_inputs = p->have_factor = 0;
@@ -401,8 +448,11 @@ static Batch batch_of(const dgp_plan* p) {
 template <typename T>
 static int run_gram(dgp_plan* p, const double* theta, const void* noise, hipStream_t s) {
   p->pre_ready = 1;
-  return gram_sym<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)noise, (T*)p->A, s,
-                     batch_of<T>(p), p->pre);
+  void* staging = p->pre ? p->ring.acquire(pre_scratch_bytes(p->B)) : nullptr;
+  const int rc = gram_sym<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)noise, (T*)p->A, s,
+                             batch_of<T>(p), p->pre, staging);
+  if (staging) p->ring.commit(s);
+  return rc;
 }
 template <typename T>
 static int run_potrf(dgp_plan* p, hipStream_t s) {
@@ -637,7 +687,24 @@ static int mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m,
   if (!(p)) return fail(DGP_E_ARG, "null plan");                                 \
   if (!(p)->ws) return fail(DGP_E_WORKSPACE, "plan has no workspace: call dgp_plan_set_workspace")
 #define DGP_SINGLE_SITE(p) \
-  if ((p)->B != 1) return fail(DGP_E_STATE, "batched plans support dgp_set_inputs / dgp_fit_step / dgp_factorize only")
+  if ((p)->B != 1)         \
+  return fail(DGP_E_STATE, "batched plans support dgp_set_inputs / dgp_fit_step / dgp_factorize / dgp_predict / dgp_predict_mean only")
+// Site b of a batched plan as a single-site plan: a shallow copy whose buffers point into that site's slice of the
+// workspace and whose n is the site's own size (ragged batches).  Never destroyed; owns nothing.
+static dgp_plan site_view(const dgp_plan* p, int b) {
+  dgp_plan v = *p;
+  if (p->B == 1) return v;
+  const size_t off = p->site_bytes * (size_t)b;
+  auto shift = [&](void* q) { return (void*)((char*)q + off); };
+  v.Xt = shift(p->Xt); v.A = shift(p->A); v.Tm = shift(p->Tm); v.S = shift(p->S); v.z = shift(p->z);
+  v.alpha = shift(p->alpha); v.gpart = shift(p->gpart); v.spart = shift(p->spart); v.scal = shift(p->scal);
+  v.info = (int*)shift(p->info);
+  v.B = 1;
+  v.n = p->nsite_host ? p->nsite_host[b] : p->n;
+  v.nsite = nullptr;
+  v.pre = nullptr;
+  return v;
+}
 static int wrap(int rc, const char* where) {
   if (rc > 0) return hipfail((hipError_t)rc, where);
   if (rc < 0) return fail(rc, where);
@@ -707,13 +774,18 @@ size_t dgp_predict_workspace_bytes(const dgp_plan* p, int64_t m) {
 int dgp_predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
                 void* mean, void* var, void* stream) {
   DGP_CHECK_PLAN(p);
-  DGP_SINGLE_SITE(p);
   if (!theta || !Xs || !work || !mean || !var || m <= 0) return fail(DGP_E_ARG, "dgp_predict: null argument");
   if (!p->have_factor) return fail(DGP_E_STATE, "dgp_predict: no factorisation in the plan (call dgp_factorize)");
   if (work_bytes < dgp_predict_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_predict: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int rc = DGP_BY_DTYPE(p, predict<double>(p, theta, Xs, m, work, mean, var, s),
-                        predict<float>(p, theta, Xs, m, work, mean, var, s));
+  int rc = 0;
+  for (int b = 0; b < p->B && !rc; ++b) {  // the sites share `work`: their launches follow each other on the stream
+    dgp_plan v = site_view(p, b);
+    const size_t xo = (size_t)b * (size_t)m * p->d * p->elem, vo = (size_t)b * (size_t)m * p->elem;
+    const double* th = theta + (size_t)b * p->ntheta;
+    rc = DGP_BY_DTYPE(p, predict<double>(&v, th, (const char*)Xs + xo, m, work, (char*)mean + vo, (char*)var + vo, s),
+                      predict<float>(&v, th, (const char*)Xs + xo, m, work, (char*)mean + vo, (char*)var + vo, s));
+  }
   return wrap(rc, "dgp_predict");
 }
 
@@ -735,13 +807,19 @@ size_t dgp_mean_vjp_workspace_bytes(const dgp_plan* p, int64_t m) { return (p &&
 int dgp_predict_mean(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
                      void* mean, void* stream) {
   DGP_CHECK_PLAN(p);
-  DGP_SINGLE_SITE(p);
   if (!theta || !Xs || !work || !mean || m <= 0) return fail(DGP_E_ARG, "dgp_predict_mean: null argument");
   if (!p->have_factor) return fail(DGP_E_STATE, "dgp_predict_mean: no factorisation in the plan");
   if (work_bytes < dgp_mean_vjp_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_predict_mean: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  return wrap(DGP_BY_DTYPE(p, predict_mean<double>(p, theta, Xs, m, work, mean, s),
-                           predict_mean<float>(p, theta, Xs, m, work, mean, s)), "dgp_predict_mean");
+  int rc = 0;
+  for (int b = 0; b < p->B && !rc; ++b) {
+    dgp_plan v = site_view(p, b);
+    const size_t xo = (size_t)b * (size_t)m * p->d * p->elem, vo = (size_t)b * (size_t)m * p->elem;
+    const double* th = theta + (size_t)b * p->ntheta;
+    rc = DGP_BY_DTYPE(p, predict_mean<double>(&v, th, (const char*)Xs + xo, m, work, (char*)mean + vo, s),
+                      predict_mean<float>(&v, th, (const char*)Xs + xo, m, work, (char*)mean + vo, s));
+  }
+  return wrap(rc, "dgp_predict_mean");
 }
 
 int dgp_mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m, const void* wts, void* work,
@@ -755,6 +833,19 @@ int dgp_mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m, co
   hipStream_t s = (hipStream_t)stream;
   return wrap(DGP_BY_DTYPE(p, mean_vjp<double>(p, theta, Xs, m, wts, work, dtheta, dr, dnoise, s),
                            mean_vjp<float>(p, theta, Xs, m, wts, work, dtheta, dr, dnoise, s)), "dgp_mean_vjp");
+}
+
+int dgp_sample_draws(int dtype, const void* L, int64_t m, const void* Z, int64_t ndraw, const void* mean, void* out,
+                     void* stream) {
+  if (dtype != DGP_F64 && dtype != DGP_F32) return fail(DGP_E_ARG, "dgp_sample_draws: dtype must be 0 (f64) or 1 (f32)");
+  if (!L || !Z || !out || m <= 0 || ndraw <= 0 || m > (1 << 20) || ndraw > (1 << 24))
+    return fail(DGP_E_ARG, "dgp_sample_draws: null argument / bad size");
+  const long M = round_up(m, DGP_TILE_HOST), Q = round_up(ndraw, DGP_TILE_HOST);
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = dtype == DGP_F64
+                     ? sample_draws<double>((const double*)L, M, (const double*)Z, Q, (const double*)mean, (int)m, (int)ndraw, (double*)out, s)
+                     : sample_draws<float>((const float*)L, M, (const float*)Z, Q, (const float*)mean, (int)m, (int)ndraw, (float*)out, s);
+  return wrap(rc, "dgp_sample_draws");
 }
 
 int dgp_plan_set_timing(dgp_plan* p, int enabled) {

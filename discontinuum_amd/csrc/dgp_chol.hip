@@ -886,8 +886,38 @@ int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Draws from N(mean, L L^T) for sample() (src/discontinuum/engines/gpytorch.py:575-580, `f_preds.sample`):
+//     out[q][j] = mean[j] + sum_{k <= j} L[j][k] Z[k][q]
+// as the transposed product Z^T L^T, so that the draw-major output rows are written contiguously: operand A = Z read
+// transposed (op(q, k) = Z[k ldz + q]), operand B = L by rows (op(j, k) = L[j ld + k]); the k-range of point block bj
+// stops at its diagonal block (the factorisation leaves zeros above the diagonal inside it).  Loads need no bounds:
+// L is M x M with the identity pad, Z is M x Q with Q % 128 == 0; only the stores are clipped to ndraw x m.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void sample_draws_kernel(const T* __restrict__ L, long ld, const T* __restrict__ Z,
+                                                              long ldz, const T* __restrict__ mean, int m, int ndraw,
+                                                              T* __restrict__ out) {
+  using G = TileGemm<T, false, true>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  const int bq = blockIdx.x, bj = gridDim.y - 1 - blockIdx.y;  // longest k-ranges first
+  typename G::acc_t acc[G::MI][G::NI];
+  G::zero(acc);
+  G::run(Z + (long)bq * NB, ldz, L + (long)bj * NB * ld, ld, (bj + 1) * (NB / 16), smem, acc);
+  G::foreach (acc, [&](int r, int c, T& v) {
+    const long q = (long)bq * NB + r, j = (long)bj * NB + c;
+    if (q < ndraw && j < m) out[q * m + j] = v + (mean ? mean[j] : T(0));
+  });
+}
+
+template <typename T>
+int sample_draws(const T* L, long M, const T* Z, long Q, const T* mean, int m, int ndraw, T* out, hipStream_t s) {
+  sample_draws_kernel<T><<<dim3((unsigned)(Q / NB), (unsigned)(M / NB)), 256, 0, s>>>(L, M, Z, Q, mean, m, ndraw, out);
+  return (int)hipGetLastError();
+}
+
 #define DGP_INST(T)                                                                                              \
   template int posterior_cov<T>(const T*, long, long, T*, hipStream_t);                                          \
+  template int sample_draws<T>(const T*, long, const T*, long, const T*, int, int, T*, hipStream_t);             \
   template int symv_lower<T>(const T*, long, const T*, int, const T*, T*, T*, T*, hipStream_t);                  \
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \
                         const int*, hipEvent_t*, void (*)(void*, int), void*, Batch);                                                                                        \

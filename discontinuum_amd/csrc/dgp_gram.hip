@@ -343,13 +343,13 @@ int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s, Batch bt) {
 
 template <typename T>
 int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s,
-             Batch bt, void* pre_scratch) {
+             Batch bt, void* pre_scratch, void* pre_staging) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
   const long nb = N / 64;
   const unsigned grid = (unsigned)(nb * (nb + 1) / 2);
   DGP_DISPATCH_MODEL(model, d, (gram_sym_kernel<T, M><<<dim3(grid, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
-                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, true, s), noise, K, bt.ws, bt.ns)));
+                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, true, s, pre_staging), noise, K, bt.ws, bt.ns)));
   return (int)hipGetLastError();
 }
 
@@ -379,14 +379,15 @@ long gram_grad_partials(long N) {
 
 template <typename T>
 int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
-              T* partials, T* dtheta, hipStream_t s, Batch bt, long dtheta_stride, void* pre_scratch, bool pre_ready) {
+              T* partials, T* dtheta, hipStream_t s, Batch bt, long dtheta_stride, void* pre_scratch, bool pre_ready,
+              void* pre_staging) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
   const long nb = N / 64;
   const long nblk = nb * (nb + 1) / 2;
   DGP_DISPATCH_MODEL(model, d,
                      (gram_grad_kernel<T, M, 0><<<dim3((unsigned)nblk, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
-                         Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, !pre_ready, s), S, alpha, nullptr,
+                         Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, !pre_ready, s, pre_staging), S, alpha, nullptr,
                          partials, bt.ws, bt.ns)));
   grad_reduce_kernel<T><<<dim3((unsigned)nt, 1, (unsigned)bt.B), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, bt.ws,
                                                                                  dtheta_stride);
@@ -421,11 +422,11 @@ int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream
 
 #define DGP_INST(T)                                                                                              \
   template int pack_x<T>(const T*, int, int, long, T*, hipStream_t, Batch);                                      \
-  template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t, Batch, void*); \
+  template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t, Batch, void*, void*); \
   template int gram_cross<T>(int, int, const T*, long, int, const T*, long, int, const double*, T*, hipStream_t); \
   template int gram_diag<T>(int, int, const T*, long, int, const double*, T*, hipStream_t);                      \
   template int gram_grad<T>(int, int, const T*, long, int, const double*, const T*, const T*, T*, T*, hipStream_t, Batch, \
-                            long, void*, bool);                                                                \
+                            long, void*, bool, void*);                                                         \
   template int mean_vjp_grad<T>(int, int, const T*, long, int, const T*, long, int, const double*, const T*, const T*, \
                                 const T*, T*, T*, hipStream_t);                                                    \
   template int gemv_rows<T>(const T*, long, long, int, const T*, T*, hipStream_t);

@@ -26,7 +26,8 @@ template <typename T>
 int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s, Batch bt = Batch());
 template <typename T>
 int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s,
-             Batch bt = Batch(), void* pre_scratch = nullptr /* pre_scratch_bytes(B) of device memory, B > 8 */);
+             Batch bt = Batch(), void* pre_scratch = nullptr /* pre_scratch_bytes(B) of device memory, B > 8 */,
+             void* pre_staging = nullptr /* pinned host memory of the same size that outlives the copy, or null: blocking copy */);
 template <typename T>
 int gram_cross(int model, int d, const T* Xt, long N, int n, const T* Xst, long M, int m, const double* theta,
                T* Ks, hipStream_t s);
@@ -35,7 +36,8 @@ int gram_diag(int model, int d, const T* Xst, long M, int m, const double* theta
 template <typename T>
 int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
               T* partials, T* dtheta, hipStream_t s, Batch bt = Batch(), long dtheta_stride = 0,
-              void* pre_scratch = nullptr, bool pre_ready = false /* gram_sym of this step filled pre_scratch */);
+              void* pre_scratch = nullptr, bool pre_ready = false /* gram_sym of this step filled pre_scratch */,
+              void* pre_staging = nullptr);
 size_t pre_scratch_bytes(int B);  // device scratch for the hyperparameters of a batch of B (0 up to 8)
 long gram_grad_partials(long N);
 template <typename T>
@@ -96,5 +98,9 @@ int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T
 // cov (M x M) = Kss - V^T V, lower tiles; Kss already holds K(Xs, Xs) (identity pad)
 template <typename T>
 int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s);
+
+// out (ndraw x m) = mean + (L Z)^T : L is M x M lower (identity pad), Z is M x Q standard normals, Q % 128 == 0
+template <typename T>
+int sample_draws(const T* L, long M, const T* Z, long Q, const T* mean, int m, int ndraw, T* out, hipStream_t s);
 
 }  // namespace dgp

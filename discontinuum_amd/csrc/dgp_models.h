@@ -274,9 +274,13 @@ struct PreBatch {
 };
 // bytes of device scratch a batch of B needs for its hyperparameters (0: they fit the argument segment)
 #define DGP_PRE_SLOT_BYTES 512
-// upload = false reuses what an earlier launcher of the same fit step put into `scratch`
+// upload = false reuses what an earlier launcher of the same fit step put into `scratch`.  `staging` is PINNED host
+// memory of at least B slots that stays untouched until the copy has run (the API layer hands out a ring slot per step,
+// dgp_api.hip::PinnedRing); without it the upload is a blocking copy -- never an asynchronous copy from pageable memory
+// whose lifetime ends with this call.
 template <typename M>
-inline PreBatch<M> prepare_batch(const double* theta, int ntheta, int B, void* scratch, bool upload, hipStream_t s) {
+inline PreBatch<M> prepare_batch(const double* theta, int ntheta, int B, void* scratch, bool upload, hipStream_t s,
+                                 void* staging = nullptr) {
   static_assert(sizeof(typename M::Pre) <= DGP_PRE_SLOT_BYTES, "Pre does not fit its scratch slot");
   PreBatch<M> pb;
   pb.dev = nullptr;
@@ -287,10 +291,17 @@ inline PreBatch<M> prepare_batch(const double* theta, int ntheta, int B, void* s
   for (int b = 0; b < DGP_MAX_BATCH; ++b) pb.p[b] = M::prepare(theta);
   pb.dev = (const typename M::Pre*)scratch;
   if (upload) {
-    // pageable source: hipMemcpyAsync stages it before returning, so the vector may go out of scope
-    std::vector<typename M::Pre> host((size_t)B);
-    for (int b = 0; b < B; ++b) host[b] = M::prepare(theta + (long)b * ntheta);
-    (void)hipMemcpyAsync(scratch, host.data(), sizeof(typename M::Pre) * (size_t)B, hipMemcpyHostToDevice, s);
+    const size_t bytes = sizeof(typename M::Pre) * (size_t)B;
+    if (staging) {
+      typename M::Pre* host = (typename M::Pre*)staging;
+      for (int b = 0; b < B; ++b) host[b] = M::prepare(theta + (long)b * ntheta);
+      (void)hipMemcpyAsync(scratch, host, bytes, hipMemcpyHostToDevice, s);
+    } else {
+      std::vector<typename M::Pre> host((size_t)B);
+      for (int b = 0; b < B; ++b) host[b] = M::prepare(theta + (long)b * ntheta);
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(scratch, host.data(), bytes, hipMemcpyHostToDevice);  // blocking: the vector dies with this call
+    }
   }
   return pb;
 }

@@ -325,8 +325,10 @@ class MarginalHIP(BaseModel):
         self.model = self.build_model(x, y) if unc is None else self.build_model(x, y, unc)
 
     # ------------------------------------------------------------------ checkpointing
-    # Dictionary layout of the reference's checkpoints (engines/gpytorch.py:107-160) so that files written by either
-    # engine load in the other: state dicts of model / likelihood / optimiser / scheduler plus bookkeeping.
+    # Dictionary layout of the reference's checkpoints (engines/gpytorch.py:107-160): state dicts of model / likelihood /
+    # optimiser / scheduler plus bookkeeping, the parameters under gpytorch's raw_* names.  Cross-engine loading is NOT
+    # claimed: a reference-written file pickles its own ModelConfig class (not importable here, and never unpickled --
+    # load() reads with weights_only=True), and the buffer keys of priors / constraints are unpinned (see _load_state).
     _OPTIMIZER_KEYS = ("optimizer_state_dict", "optimizer_name", "optimizer_lr", "scheduler_state_dict", "scheduler_name")
 
     def save(self, f, optimizer_obj=None, scheduler=None, extra=None) -> None:
@@ -337,7 +339,7 @@ class MarginalHIP(BaseModel):
         sch = scheduler if scheduler is not None else getattr(self, "_last_scheduler", None)
         record = {
             "model_class": f"{type(self).__module__}.{type(self).__name__}",
-            "model_config": getattr(self, "model_config", None),
+            "model_config": self._config_record(),
             "current_iteration": getattr(self, "_current_iteration", 0),
             "extra": extra or {},
             "model_state_dict": self.model.state_dict(),
@@ -353,20 +355,48 @@ class MarginalHIP(BaseModel):
             record.update(scheduler_state_dict=sch.state_dict(), scheduler_name=type(sch).__name__)
         torch.save(record, f)
 
+    def _config_record(self):
+        """The model configuration as plain data (a checkpoint must load with ``weights_only=True``)."""
+        config = getattr(self, "model_config", None)
+        if isinstance(config, ModelConfig):
+            return {"transform": config.transform}
+        return config if isinstance(config, dict) else None
+
+    @staticmethod
+    def _load_state(module, state, what):
+        """``load_state_dict`` that insists on every PARAMETER (raw_*, the power law's a / b / c) and tolerates
+        differences in the buffers that only describe priors and constraints (``*_prior.scale``, ``*_constraint.
+        lower_bound`` ...): those are constants of the model definition, rebuilt by ``build_model``, and whether a prior
+        registers them as buffers differs between gpytorch versions -- the gpytorch side of this boundary is parity
+        unpinned."""
+        result = module.load_state_dict(state, strict=False)
+        params = {name for name, _ in module.named_parameters()}
+        missing = [k for k in result.missing_keys if k in params]
+        unexpected = [k for k in result.unexpected_keys
+                      if k.rsplit(".", 1)[-1].startswith("raw_") or "powerlaw" in k or "mean_module" in k]
+        if missing or unexpected:
+            raise RuntimeError(f"{what} state does not match this model: missing parameters {missing}, "
+                               f"unexpected parameters {unexpected}")
+
     @classmethod
     def load(cls, f, covariates, target, target_unc=None):
         """A model restored from ``save()`` output and re-attached to its data: ready to predict, or to continue
-        training with ``fit(..., resume=True)`` (engines/gpytorch.py:47-105)."""
-        record = torch.load(f, map_location="cpu", weights_only=False)
+        training with ``fit(..., resume=True)`` (engines/gpytorch.py:47-105).  The file is read with
+        ``weights_only=True`` (nothing in it is executed); checkpoints of earlier versions that pickled the
+        ``ModelConfig`` dataclass load under an allow-list of exactly that class."""
+        with torch.serialization.safe_globals([ModelConfig]):
+            record = torch.load(f, map_location="cpu", weights_only=True)
         # the reference rebuilds with the default configuration and ignores the one it saved (engines/gpytorch.py:69);
         # a model trained with transform="standard" would come back in the wrong data space, so the saved one is used
         saved_config = record.get("model_config")
+        if isinstance(saved_config, dict) and "transform" in saved_config:
+            saved_config = ModelConfig(transform=saved_config["transform"])
         self = cls(model_config=saved_config) if isinstance(saved_config, ModelConfig) else cls()
         x, y, unc = self._attach(covariates, target, target_unc)
         self._fresh_model(x, y, unc)
-        self.model.load_state_dict(record["model_state_dict"])
+        self._load_state(self.model, record["model_state_dict"], "model")
         if record.get("likelihood_state_dict") is not None:
-            self.likelihood.load_state_dict(record["likelihood_state_dict"])
+            self._load_state(self.likelihood, record["likelihood_state_dict"], "likelihood")
         self._current_iteration = record.get("current_iteration", 0)
         self._resume_info = {key: record.get(key) for key in cls._OPTIMIZER_KEYS}
         self._resume_info["current_iteration"] = self._current_iteration
@@ -598,7 +628,8 @@ class MarginalHIP(BaseModel):
     @is_fitted
     def sample(self, covariates, n=1000):
         """Draws from the latent posterior (engines/gpytorch.py:551-593): full m x m covariance
-        K** - V^T V with V = L^-1 K(X, X*), its Cholesky factor (our blocked HIP potrf) times N(0, I)."""
+        K** - V^T V with V = L^-1 K(X, X*), its Cholesky factor (our blocked HIP potrf, psd_safe_cholesky's jitter
+        policy) times N(0, I) (``dgp_sample_draws``)."""
         Xnew = torch.tensor(self.dm.Xnew(covariates), dtype=self.dtype).to(self.device).contiguous()
         self._device_ready()
         self.model.eval()
@@ -607,10 +638,9 @@ class MarginalHIP(BaseModel):
             if hasattr(self.model, "prepare_eval"):
                 self.model.prepare_eval(self._train_x, Xnew)
             self._ensure_factor()
-            mean, cov_factor = self._plan.posterior_factor(self._factor_theta, Xnew)
+            mean, factor, _jitter = self._plan.posterior_factor(self._factor_theta, Xnew)
             mean = mean + self.model.prior_mean(Xnew)
-            z = torch.randn(cov_factor.shape[0], n, dtype=self.dtype, device=cov_factor.device)
-            sim = (mean[:, None] + cov_factor @ z).T.contiguous()  # (n, m)
+            sim = self._plan.sample_draws(factor, Xnew.shape[0], mean, n)  # (n, m) = mean + (L z)^T, one HIP launch
         temp = self.dm.y_t_device(sim.reshape(-1))
         data = np.asarray(temp.data).reshape(n, -1)
         return DataArray(data, coords=dict(covariates.coords, draw=np.arange(n)),

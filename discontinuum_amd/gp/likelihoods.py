@@ -57,11 +57,12 @@ class FixedNoiseGaussianLikelihood(nn.Module):
 
     def predictive_noise(self, m, device, dtype):
         """What ``likelihood(model(x))`` adds to the latent variance at m test points: the fixed part
-        only when m equals the training size (else a zero no-op with a warning), plus second_noise."""
+        only when m equals the training size (else a zero no-op -- with gpytorch's warning when there is no learned
+        second noise term either), plus second_noise."""
         add = torch.zeros(m, device=device, dtype=dtype)
         if m == self.noise.numel():
             add = add + self.noise.to(device, dtype)
-        else:
+        elif self.second_noise_covar is None:  # gpytorch warns only when there is no second noise term either
             warnings.warn(
                 "You have passed data through a FixedNoiseGaussianLikelihood that did not match the size "
                 "of the fixed noise, *and* you did not specify noise. This is treated as a no-op.",

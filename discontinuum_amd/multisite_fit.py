@@ -91,6 +91,20 @@ class _BatchedNLL(torch.autograd.Function):
         return None, (dtheta * g).to(ctx.dtypes[0]), None, None, (dextras * g).to(ctx.dtypes[1]), None
 
 
+def _per_site_clip(raw_grads: dict, B: int, max_norm: float = 1.0):
+    """``clip_grad_norm_(max_norm)`` followed by the reference's NaN scan (engines/gpytorch.py:387-400), per site, on
+    stacked gradients (leading dimension B).  The norm is taken of the RAW gradient, like the reference and
+    ``MarginalHIP.fit`` do: one NaN / Inf component makes a site's norm non-finite, the clip then turns every component
+    of that site's gradient into NaN and the scan zeroes them all -- the site steps on weight decay only.
+    -> (coef (B,), sanitised gradients); the clipped gradient of a parameter is ``grads[k] * coef`` per site."""
+    sq = sum((g.reshape(B, -1) ** 2).sum(dim=1) for g in raw_grads.values())
+    broken = ~torch.isfinite(sq)
+    coef = torch.clamp(max_norm / (torch.sqrt(torch.where(broken, torch.ones_like(sq), sq)) + 1e-6), max=1.0)
+    coef = torch.where(broken, torch.zeros_like(coef), coef)
+    grads = {k: torch.nan_to_num(g, nan=0.0, posinf=0.0, neginf=0.0) for k, g in raw_grads.items()}
+    return coef, grads
+
+
 def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.05, patience: int = 60,
              scheduler: bool = True, progress: bool = False, early_stopping: bool = False):
     """Fit ``models[i]`` to ``datasets[i] = (covariates, target[, target_unc])`` for all i at once.  Returns the
@@ -217,10 +231,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
             raise RuntimeError(f"site {int(torch.argmax(nan_run))}: more than 10 consecutive NaN/Inf objectives "
                                f"at iteration {it + 1}")
         torch.where(ok, obj, torch.zeros_like(obj)).sum().backward()
-        grads = {k: torch.nan_to_num(v.grad, nan=0.0, posinf=0.0, neginf=0.0) for k, v in params.items()}
-        # clip_grad_norm_(max_norm=1.0) per site
-        sq = sum((g.reshape(B, -1) ** 2).sum(dim=1) for g in grads.values())
-        coef = torch.clamp(1.0 / (torch.sqrt(sq) + 1e-6), max=1.0)
+        coef, grads = _per_site_clip({k: v.grad for k, v in params.items()}, B)
         okf = ok.to(torch.float64)
         step = step + okf
         bc1 = 1.0 - beta1 ** step

@@ -7,6 +7,8 @@ step order, clips and scalers, written on plain numpy (no sklearn ``Pipeline`` d
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 import torch
 import pandas as pd
@@ -167,7 +169,7 @@ def _like(value, t):
     return torch.as_tensor(np.asarray(value, dtype=np.float64).reshape(-1), dtype=t.dtype, device=t.device)
 
 
-_PINNED = {}
+_PINNED = threading.local()  # one reused buffer PER THREAD: concurrent sample() calls must not share it
 
 
 def _to_host(t):
@@ -175,10 +177,9 @@ def _to_host(t):
     if not t.is_cuda:
         return t.numpy()
     key = (t.dtype, t.numel())
-    if key not in _PINNED:
-        _PINNED.clear()
-        _PINNED[key] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
-    host = _PINNED[key]
+    if getattr(_PINNED, "key", None) != key:
+        _PINNED.key, _PINNED.buf = key, torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+    host = _PINNED.buf
     host.copy_(t.reshape(-1))
     return host.numpy().reshape(tuple(t.shape)).copy()
 

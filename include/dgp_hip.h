@@ -77,7 +77,10 @@ size_t dgp_plan_workspace_bytes(const dgp_plan* plan);
  * the sequential panel chain and the launch rate over the batch (the reference analogue is its map over sites,
  * examples/nwqn-loadest-example/nwqn-loadest-example.py:156-159).  The workspace grows by the same factor and the
  * arrays of dgp_set_inputs / dgp_fit_step / dgp_factorize become batch-major: X[batch][n][d], theta[batch][ntheta],
- * r / noise / dr / dnoise [batch][n], out[batch][DGP_OUT_LEN].  The inference entry points need batch == 1. */
+ * r / noise / dr / dnoise [batch][n], out[batch][DGP_OUT_LEN].  dgp_predict and dgp_predict_mean also accept batched
+ * plans (every site predicts at its own m points: Xs[batch][m][d], theta[batch][ntheta] -> mean / var [batch][m]; the
+ * sites' launches follow each other on the stream and share the one workspace); the other inference entry points
+ * (dgp_posterior_cov, dgp_mean_vjp, dgp_cross_gram, the dgp_dist_* family) need batch == 1. */
 int dgp_plan_set_batch(dgp_plan* plan, int batch);
 int dgp_plan_batch(const dgp_plan* plan);
 /* Ragged batches (after dgp_plan_set_workspace, before dgp_set_inputs): site b has sizes[b] <= n observations; it
@@ -136,6 +139,16 @@ int dgp_predict(dgp_plan* plan, const double* theta_host, const void* Xs_dev, in
  * work_dev as for dgp_predict (dgp_predict_workspace_bytes). */
 int dgp_posterior_cov(dgp_plan* plan, const double* theta_host, const void* Xs_dev, int64_t m, void* work_dev,
                       size_t work_bytes, void* mean_dev, void* cov_dev, void* stream);
+
+/* Draws from N(mean, L L^T) -- what `f_preds.sample(torch.Size([n]))` does at engines/gpytorch.py:575-580:
+ *     out_dev[q][j] = mean_dev[j] + sum_{k <= j} L[j][k] Z[k][q]        (ndraw x m row-major, q = draw)
+ * L_dev   M x M row-major, M = dgp_padded_n(m): a lower-triangular factor with zeros above the diagonal inside its
+ *         diagonal 128-blocks and the identity in the pad -- e.g. DGP_BUF_A of an order-m plan after dgp_stage_potrf
+ *         of the matrix dgp_posterior_cov wrote there (blocks above the block diagonal are never read);
+ * Z_dev   M x Q row-major standard normals, Q = dgp_padded_n(ndraw) (the pad only feeds entries that are not stored);
+ * mean_dev m entries or NULL.  One MFMA launch (the same tile core as the factorisation); needs no plan. */
+int dgp_sample_draws(int dtype, const void* L_dev, int64_t m, const void* Z_dev, int64_t ndraw, const void* mean_dev,
+                     void* out_dev, void* stream);
 
 /* Predictive mean only, and its vector-Jacobian product -- what the rating-gp monotonicity penalty
  * differentiates (src/rating_gp/models/gpytorch.py:130-187: mean of likelihood(model(x_grid)) with grad).

@@ -75,8 +75,16 @@ class OraclePlan:
     def posterior_factor(self, theta, Xs):
         theta, r, noise = self._state
         mu, cov = orc.posterior(self.model, self.X, r, noise, theta, Xs.double(), full_cov=True)
-        cov = cov + 1e-8 * torch.eye(cov.shape[0], dtype=torch.float64)
-        return mu.to(self.dtype), torch.linalg.cholesky(cov).to(self.dtype)
+        eye = torch.eye(cov.shape[0], dtype=torch.float64)
+        for jitter in (0.0, 1e-8, 1e-7, 1e-6):
+            L, info = torch.linalg.cholesky_ex(cov + jitter * eye)
+            if int(info) == 0:
+                return mu.to(self.dtype), L.to(self.dtype), jitter
+        raise RuntimeError("posterior covariance not positive definite")
+
+    def sample_draws(self, L, m, mean, ndraw, generator=None):
+        z = torch.randn(m, ndraw, dtype=self.dtype, generator=generator)
+        return (mean[:, None] + L @ z).T.contiguous()
 
 
 def loadest_dataset(n=40, seed=0):

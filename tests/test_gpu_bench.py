@@ -13,9 +13,9 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 
-@pytest.mark.parametrize("extra", [[], ["--dtype", "f32", "--sites-per-gpu", "1"]])
+@pytest.mark.parametrize("extra", [[], ["--dtype", "f32", "--sites-per-gpu", "1"], ["--model", "rating", "--sites-per-gpu", "4"]])
 def test_bench_prints_one_contract_line(extra, gpu_device):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "1024", "--steps", "3", "--warmup", "1"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "1024", "--steps", "3", "--warmup", "1", "--cpu-steps", "2"] + extra
     run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stderr[-2000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
@@ -33,3 +33,6 @@ def test_bench_prints_one_contract_line(extra, gpu_device):
     assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     cpu = rec["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu
+    assert len(cpu["steps_s"]) == 2 and cpu["fp32"]["value"] > 0 and cpu["affinity_cores"] >= cpu["cores"]
+    assert "configs" not in rec  # only the default n = 8192 run carries the other BASELINE configurations
+    assert roof["gram_hbm"]["achieved"] > 0 and roof["gram_grad_hbm"]["achieved"] > 0
