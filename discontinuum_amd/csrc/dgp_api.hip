@@ -119,10 +119,15 @@ static Layout layout(const dgp_plan* p) {
 
 static int default_lookahead() { return 2; }  // lookahead on: the group-ahead schedule of dgp_chol.hip::potrf
 // panels per group of that schedule: pairs for one site (chain-bound), larger groups (K = 512 bulk updates) for a batch
-static int group_size(int lookahead, int batch) {
+// One site: pairs while the factorisation is chain-bound; from ~96 block columns on it is bound by its bulk updates, which
+// gain from a longer K per read-modify-write pass over the trailing matrix (measured, one site: n = 16384 fp32 43.1 -> 42.1 ms
+// per fit step with groups of 4, fp64 79.2 -> 77.2; n = 65536 fp32 2305 -> 2239 (4) -> 2216 ms (8); n = 8192: 12.44 -> 12.50
+// with 4).  Batched plans: 4, 6 and 8 give the same factorisation time (n = 8192 x 32: 101.7 / 101.9 / 102.5 ms).
+static int group_size(int lookahead, int batch, long nbk) {
   if (!lookahead) return 0;
   if (const char* e = getenv("DGP_GROUP")) return atoi(e) < 2 ? 2 : atoi(e);
-  return batch >= 4 ? 4 : 2;
+  if (batch >= 4) return 4;
+  return nbk >= 256 ? 8 : (nbk >= 96 ? 4 : 2);
 }
 
 // workgroups the EARLY inverse launches may occupy (one per CU): they share the GPU with the panel chain
@@ -459,7 +464,7 @@ static int run_potrf(dgp_plan* p, hipStream_t s) {
   int rc = ensure_async(p);
   if (rc) return rc;
   if ((rc = ensure_timing(p))) return rc;
-  return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B), s, p->s2, p->ev,
+  return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), s, p->s2, p->ev,
                   p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr,
                   batch_of<T>(p));
 }
@@ -522,7 +527,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
       if (rc && !e->rc) e->rc = rc;
     };
     if ((rc = ensure_timing(p))) return rc;
-    rc = potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B), s, p->s2, p->ev,
+    rc = potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), s, p->s2, p->ev,
                   p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx);
     if (rc || (rc = ctx.rc)) return rc;
     tick(p, TS_POTRF, 1, s);

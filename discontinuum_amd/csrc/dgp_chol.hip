@@ -383,10 +383,15 @@ __device__ __forceinline__ void trtri_tile(const T* __restrict__ L, T* __restric
                                            int m, int lo, int mid, int hi, int tile, T* __restrict__ smem) {
   using G = TileGemm<T, true, false, BT, BT>;
   constexpr int KT = BT / 16;  // k-tiles per tile of the reduction dimension
+  // A group that the matrix edge cuts off has R = hi - mid < m tile rows: its R m tiles are the FIRST tile indices, so
+  // that they are dealt over all XCDs (workgroup ids go round-robin over the 8 XCDs: with the full groups' i = mid + tile % m
+  // map, a group with one tile row -- 2^k + 1 block columns -- would run on every m-th id only, i.e. on ONE XCD when
+  // 8 | m: measured 126 ms instead of 5 for the top level of 65 block columns x 32 sites).
+  const int R = min(m, hi - mid);
+  if (R <= 0 || tile >= R * m) return;
   // longest k-range first: W-step K ~ (mid - j), T-step K ~ (i - mid + 1)
-  const int i = STEP == 0 ? mid + tile % m : mid + (m - 1 - tile / m);
-  const int j = STEP == 0 ? lo + tile / m : lo + tile % m;
-  if (i >= hi) return;
+  const int i = STEP == 0 ? mid + tile % R : mid + (R - 1 - tile / m);
+  const int j = STEP == 0 ? lo + tile / R : lo + tile % m;
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
   if (STEP == 0) {
