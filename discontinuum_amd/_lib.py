@@ -48,10 +48,27 @@ SIGNATURES = {
     "dgp_plan_batch": (_i, [_vp]),
     "dgp_plan_set_site_sizes": (_i, [_vp, C.POINTER(C.c_int64), _vp]),
     "dgp_plan_set_dr_weights": (_i, [_vp, _vp]),
-    "dgp_dist_begin": (_i, [_vp, _vp]),
-    "dgp_dist_factor_group": (_i, [_vp, _i, _i, _vp]),
-    "dgp_dist_update": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "dgp_dist_finish": (_i, [_vp, _vp, C.c_double, _i, _vp, _vp]),
+    "dgp_dist_last_error": (C.c_char_p, []),
+    "dgp_dist_create": (_i, [_i, _i, _i64, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "dgp_dist_destroy": (_i, [_vp]),
+    "dgp_dist_padded_n": (_i64, [_vp]),
+    "dgp_dist_groups": (_i, [_vp]),
+    "dgp_dist_slab_columns": (_i64, [_vp]),
+    "dgp_dist_workspace_bytes": (_sz, [_vp]),
+    "dgp_dist_panel_elems": (_sz, [_vp, _i]),
+    "dgp_dist_set_workspace": (_i, [_vp, _vp, _sz]),
+    "dgp_dist_set_inputs": (_i, [_vp, _vp, _vp]),
+    "dgp_dist_gram": (_i, [_vp, _dp, _vp, _vp]),
+    "dgp_dist_factor": (_i, [_vp, _i, _vp, _vp]),
+    "dgp_dist_update": (_i, [_vp, _i, _vp, _i, _i, _vp]),
+    "dgp_dist_invert": (_i, [_vp, _i, _vp, _vp]),
+    "dgp_dist_status": (_i, [_vp, _vp, _vp]),
+    "dgp_dist_solve_partial": (_i, [_vp, _vp, _vp, _vp]),
+    "dgp_dist_alpha_partial": (_i, [_vp, _vp, _vp, _vp]),
+    "dgp_dist_pack_inverse": (_i, [_vp, _i, _vp, _vp]),
+    "dgp_dist_product": (_i, [_vp, _i, _vp, _vp]),
+    "dgp_dist_grad_partial": (_i, [_vp, _dp, _vp, _vp, _vp, _vp]),
+    "dgp_dist_slab": (_i, [_vp, _i, C.POINTER(_vp)]),
     "dgp_plan_buffer": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64)]),
     "dgp_set_inputs": (_i, [_vp, _vp, _vp]),
     "dgp_fit_step": (_i, [_vp, _dp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -101,5 +118,6 @@ def load():
 
 def check(rc, where):
     if rc != 0:
-        msg = load().dgp_last_error().decode("utf-8", "replace")
-        raise DGPError(rc, where, msg)
+        lib = load()
+        err = lib.dgp_dist_last_error if where.startswith("dgp_dist_") else lib.dgp_last_error
+        raise DGPError(rc, where, err().decode("utf-8", "replace"))

@@ -326,36 +326,6 @@ class GPPlan:
         _lib.check(self.lib.dgp_plan_buffer(self._h, 6, C.byref(p), C.byref(ld)), "dgp_plan_buffer")
         return p.value - self._ws.data_ptr()
 
-    # ------------------------------------------------------------------ one matrix over several GPUs (dist_chol.py)
-    def local_logdet(self) -> float:
-        """log-determinant accumulated by this plan's diagonal-block kernels since ``dist_begin`` (synchronising)."""
-        p, ld = C.c_void_p(), C.c_int64()
-        _lib.check(self.lib.dgp_plan_buffer(self._h, _lib.BUF_SCAL, C.byref(p), C.byref(ld)), "dgp_plan_buffer")
-        off = p.value - self._ws.data_ptr()
-        esz = torch.empty((), dtype=self.dtype).element_size()
-        return float(self._ws[off:off + esz].view(self.dtype)[0].item())
-
-    def dist_begin(self):
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.dgp_dist_begin(self._h, _stream()), "dgp_dist_begin")
-
-    def dist_factor_group(self, first_block: int, nblocks: int):
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.dgp_dist_factor_group(self._h, first_block, nblocks, _stream()), "dgp_dist_factor_group")
-
-    def dist_update(self, first_block: int, nblocks: int, rank: int, world: int, col_begin: int = 0, col_end: int = 0):
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.dgp_dist_update(self._h, first_block, nblocks, rank, world, col_begin, col_end, _stream()),
-                       "dgp_dist_update")
-
-    def dist_finish(self, r: torch.Tensor, logdet_total: float, info_total: int):
-        self._check_vec(r, "r")
-        with torch.cuda.device(self.device):
-            out = torch.empty(_lib.OUT_LEN, dtype=self.dtype, device=self.device)
-            _lib.check(self.lib.dgp_dist_finish(self._h, _ptr(r), float(logdet_total), int(info_total), _ptr(out), _stream()),
-                       "dgp_dist_finish")
-        return out
-
     def set_timing(self, enabled: bool):
         _lib.check(self.lib.dgp_plan_set_timing(self._h, int(bool(enabled))), "dgp_plan_set_timing")
 

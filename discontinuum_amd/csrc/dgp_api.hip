@@ -716,25 +716,6 @@ static int wrap(int rc, const char* where) {
   return 0;
 }
 
-template <typename T>
-__global__ void dist_begin_kernel(T* scal, int* info) {
-  scal[0] = T(0);
-  scal[1] = T(0);
-  info[0] = 0;
-}
-template <typename T>
-__global__ void dist_assemble_kernel(const T* scal, double logdet_total, int info_total, long n, T* out) {
-  const int t = threadIdx.x;
-  if (t == 0) {
-    const T quad = scal[1];
-    out[DGP_OUT_NLL] = T(0.5) * quad + T(0.5 * logdet_total) + T(0.5 * 1.83787706640934548356) * (T)n;
-    out[DGP_OUT_QUAD] = quad;
-    out[DGP_OUT_LOGDET] = (T)logdet_total;
-    out[DGP_OUT_INFO] = (T)info_total;
-  }
-  if (t >= DGP_OUT_DTHETA && t < DGP_OUT_LEN) out[t] = T(0);
-}
-
 extern "C" {
 
 int dgp_set_inputs(dgp_plan* p, const void* X, void* stream) {
@@ -933,61 +914,6 @@ int dgp_cross_gram(dgp_plan* p, const double* theta, const void* Xs, int64_t m, 
   hipStream_t s = (hipStream_t)stream;
   return wrap(DGP_BY_DTYPE(p, cross<double>(p, theta, Xs, m, work, Ks, s), cross<float>(p, theta, Xs, m, work, Ks, s)),
               "dgp_cross_gram");
-}
-
-// ---- one matrix distributed over several GPUs (include/dgp_hip.h: dgp_dist_*) -----------------------
-int dgp_dist_begin(dgp_plan* p, void* stream) {
-  DGP_CHECK_PLAN(p);
-  DGP_SINGLE_SITE(p);
-  hipStream_t s = (hipStream_t)stream;
-  if (p->dtype == DGP_F64) dist_begin_kernel<double><<<1, 1, 0, s>>>((double*)p->scal, p->info);
-  else dist_begin_kernel<float><<<1, 1, 0, s>>>((float*)p->scal, p->info);
-  p->have_factor = 0;
-  return wrap((int)hipGetLastError(), "dgp_dist_begin");
-}
-
-int dgp_dist_factor_group(dgp_plan* p, int first_block, int nblocks, void* stream) {
-  DGP_CHECK_PLAN(p);
-  DGP_SINGLE_SITE(p);
-  const int nbk = (int)(p->N / DGP_TILE_HOST);
-  if (first_block < 0 || nblocks < 1 || first_block >= nbk) return fail(DGP_E_ARG, "dgp_dist_factor_group: bad block range");
-  hipStream_t s = (hipStream_t)stream;
-  int rc = DGP_BY_DTYPE(p, potrf_group<double>((double*)p->A, p->N, (double*)p->Tm, (double*)p->scal, p->info, first_block, nblocks, s),
-                        potrf_group<float>((float*)p->A, p->N, (float*)p->Tm, (float*)p->scal, p->info, first_block, nblocks, s));
-  return wrap(rc, "dgp_dist_factor_group");
-}
-
-int dgp_dist_update(dgp_plan* p, int first_block, int nblocks, int rank, int world, int col_begin, int col_end,
-                    void* stream) {
-  DGP_CHECK_PLAN(p);
-  DGP_SINGLE_SITE(p);
-  const int nbk = (int)(p->N / DGP_TILE_HOST);
-  if (first_block < 0 || nblocks < 1 || first_block >= nbk || first_block % nblocks != 0 || world < 1 || rank < 0 || rank >= world)
-    return fail(DGP_E_ARG, "dgp_dist_update: bad block range / rank");
-  hipStream_t s = (hipStream_t)stream;
-  if (col_end <= 0) col_end = nbk;
-  int rc = DGP_BY_DTYPE(p, syrk_owned<double>((double*)p->A, p->N, first_block, nblocks, rank, world, col_begin, col_end, s),
-                        syrk_owned<float>((float*)p->A, p->N, first_block, nblocks, rank, world, col_begin, col_end, s));
-  return wrap(rc, "dgp_dist_update");
-}
-
-int dgp_dist_finish(dgp_plan* p, const void* r, double logdet_total, int info_total, void* out, void* stream) {
-  DGP_CHECK_PLAN(p);
-  DGP_SINGLE_SITE(p);
-  if (!r || !out) return fail(DGP_E_ARG, "dgp_dist_finish: null argument");
-  hipStream_t s = (hipStream_t)stream;
-  int rc;
-  if (p->dtype == DGP_F64) {
-    rc = trsv_lower<double>((const double*)p->A, (const double*)p->Tm, p->N, (const double*)r, (int)p->n, (double*)p->z, (double*)p->spart,
-                            (double*)p->scal + 1, s);
-    dist_assemble_kernel<double><<<1, 64, 0, s>>>((const double*)p->scal, logdet_total, info_total, (long)p->n, (double*)out);
-  } else {
-    rc = trsv_lower<float>((const float*)p->A, (const float*)p->Tm, p->N, (const float*)r, (int)p->n, (float*)p->z, (float*)p->spart,
-                           (float*)p->scal + 1, s);
-    dist_assemble_kernel<float><<<1, 64, 0, s>>>((const float*)p->scal, logdet_total, info_total, (long)p->n, (float*)out);
-  }
-  if (!rc) rc = (int)hipGetLastError();
-  return wrap(rc, "dgp_dist_finish");
 }
 
 }  // extern "C"

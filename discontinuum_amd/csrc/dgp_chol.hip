@@ -250,124 +250,19 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------
-// Building blocks of the factorisation of ONE matrix distributed over several GPUs (BASELINE config 5, SURVEY
-// section 8e): block columns are dealt to the ranks in groups of W panels (1-D block-cyclic); every rank holds a
-// full-size A but only its own groups are kept up to date.  For group g (owner g % world):
-//     owner:      potrf_group      -- the panel chain of the group's W columns (all rows below)
-//     all ranks:  receive the factored columns (the host side broadcasts rows >= k0 of those columns)
-//     all ranks:  syrk_owned       -- their own block columns right of the group <- the group's panels (K = 128 W),
-//                                     optionally only those in [jb0, jb1) (lookahead: the next group's columns first)
-// After the last group every rank holds all of L and the inverses of its diagonal blocks (they travel with the
-// panels); the forward solve for the NLL (trsv_lower) needs nothing else.
+// The panel chain of W consecutive block columns starting at block column k0, on a matrix addressed through
+// (A, ld) -- the owner's step of the DISTRIBUTED factorisation (dgp_dist.hip), where A points into a rank's column
+// slab such that A[r * ld + c] is the global element (r, c) for the columns of this group: every kernel of the chain
+// only touches columns of the group, so the single-GPU kernels apply unchanged.  Tinv likewise (L_kk^-1 lands in
+// its diagonal blocks).
 template <typename T>
-int potrf_group(T* A, long N, T* Tinv, T* logdet, int* info, int k0, int W, hipStream_t s) {
-  const int nbk = (int)(N / NB);
+int potrf_group(T* A, long ld, int nbk, T* Tinv, T* logdet, int* info, int k0, int W, hipStream_t s) {
   const Batch bt;
   for (int h = 0; h < W && k0 + h < nbk; ++h) {
     const int k = k0 + h;
-    if (h >= 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2, 1), 256, 0, s>>>(A, N, k0, h, k, nbk, 1, 0);
-    launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt);
-    if (k + 1 < nbk) trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, 1), 256, 0, s>>>(A, Tinv, N, k, 0);
-  }
-  return (int)hipGetLastError();
-}
-
-// tile (i, j) of an OWNED block column j > the group: blockIdx.y enumerates the owned columns right of the group
-// (groups g' = gfirst, gfirst + world, ... of W columns each), blockIdx.x the block rows from the diagonal down
-template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_owned_kernel(T* __restrict__ A, long ld, int k0, int nk, int W, int nbk,
-                                                            int gfirst, int world, int jb0, int jb1) {
-  __shared__ T smem[TileGemm<T, true, true>::SMEM_ELEMS];
-  const int t = (int)blockIdx.y;
-  const int bj = (gfirst + (t / W) * world) * W + t % W;
-  const int bi = bj + (int)blockIdx.x;
-  if (bj >= nbk || bi >= nbk || bj < jb0 || bj >= jb1) return;
-  syrk_tile<T, 128, 128>(A, ld, k0, nk, (long)bi * NB, (long)bj * NB, smem);
-}
-
-template <typename T>
-int syrk_owned(T* A, long N, int k0, int W, int rank, int world, int jb0, int jb1, hipStream_t s) {
-  const int nbk = (int)(N / NB);
-  const int g = k0 / W;
-  int gfirst = g + 1;
-  while (gfirst % world != rank) ++gfirst;
-  if (gfirst * W >= nbk) return 0;  // nothing of this rank's right of the group
-  const int ngroups = (nbk - gfirst * W + world * W - 1) / (world * W);  // owned groups from gfirst on
-  const int wk = (k0 + W <= nbk) ? W : nbk - k0;
-  syrk_owned_kernel<T><<<dim3((unsigned)(nbk - gfirst * W), (unsigned)(ngroups * W), 1), 256, 0, s>>>(A, N, k0, wk, W, nbk,
-                                                                                                     gfirst, world, jb0, jb1);
-  return (int)hipGetLastError();
-}
-
-// z = L^-1 r by block rows (forward substitution), quad = z^T z.  Block row k: partial dot products of L[k, :k] with
-// z[:k] over column chunks (many workgroups), then ONE workgroup sums them in a fixed order and applies the inverse
-// of the 128 x 128 diagonal block.  O(N^2) flops, N/128 dependent steps.
-#define DGP_TRSV_CHUNK 2048
-template <typename T>
-__global__ __launch_bounds__(256) void trsv_dot_kernel(const T* __restrict__ L, long ld, int k, const T* __restrict__ z,
-                                                       T* __restrict__ partial) {
-  // workgroup (c, q): columns [c * CHUNK, min((c+1) * CHUNK, k * 128)), rows 4q .. 4q+3 of the block row, one wave each;
-  // four independent loads in flight per lane (the step is latency-bound, not bandwidth-bound)
-  const int lane = threadIdx.x & 63, rr = (int)blockIdx.y * 4 + (threadIdx.x >> 6);
-  const long c0 = (long)blockIdx.x * DGP_TRSV_CHUNK;
-  const long c1 = min(c0 + (long)DGP_TRSV_CHUNK, (long)k * NB);
-  const T* row = L + ((long)k * NB + rr) * ld;
-  T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
-  long j = c0 + lane;
-  for (; j + 192 < c1; j += 256) {
-    a0 += row[j] * z[j];
-    a1 += row[j + 64] * z[j + 64];
-    a2 += row[j + 128] * z[j + 128];
-    a3 += row[j + 192] * z[j + 192];
-  }
-  for (; j < c1; j += 64) a0 += row[j] * z[j];
-  const T acc = wave_sum((a0 + a1) + (a2 + a3));
-  if (lane == 0) partial[(long)blockIdx.x * NB + rr] = acc;
-}
-
-// z_k = L_kk^-1 (r_k - sum of the partials), with the block's inverse from the diagonal-block kernel (T's diagonal
-// blocks; the distributed driver broadcasts them with the panels): a 128 x 128 lower-triangular matvec, one wave per
-// row group, fixed summation order.
-template <typename T>
-__global__ __launch_bounds__(256) void trsv_solve_kernel(const T* __restrict__ Tinv, long ld, int k, int nchunks,
-                                                         const T* __restrict__ partial, const T* __restrict__ r, int n,
-                                                         T* __restrict__ z, T* __restrict__ quad) {
-  __shared__ T v[NB];
-  __shared__ T y[NB];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (t < NB) {
-    const long gi = (long)k * NB + t;
-    T x = gi < n ? r[gi] : T(0);
-    for (int c = 0; c < nchunks; ++c) x -= partial[(long)c * NB + t];
-    v[t] = x;
-  }
-  __syncthreads();
-  const T* Tkk = Tinv + (long)k * NB * ld + (long)k * NB;
-  for (int rr = wv; rr < NB; rr += 4) {  // row rr: sum_{j <= rr} Tkk[rr][j] v[j]
-    const T* row = Tkk + (long)rr * ld;
-    T acc = T(0);
-    for (int j = lane; j <= rr; j += 64) acc += row[j] * v[j];
-    acc = wave_sum(acc);
-    if (lane == 0) y[rr] = acc;
-  }
-  __syncthreads();
-  if (t < NB) z[(long)k * NB + t] = y[t];
-  if (wv == 0) {
-    T q = y[lane] * y[lane] + y[lane + 64] * y[lane + 64];
-    q = wave_sum(q);
-    if (lane == 0) quad[0] = (k == 0 ? T(0) : quad[0]) + q;
-  }
-}
-
-long trsv_partials(long N) { return (N + DGP_TRSV_CHUNK - 1) / DGP_TRSV_CHUNK * NB; }
-
-template <typename T>
-int trsv_lower(const T* L, const T* Tinv, long N, const T* r, int n, T* z, T* partials, T* quad, hipStream_t s) {
-  const int nbk = (int)(N / NB);
-  for (int k = 0; k < nbk; ++k) {
-    const int nchunks = (int)(((long)k * NB + DGP_TRSV_CHUNK - 1) / DGP_TRSV_CHUNK);
-    if (nchunks > 0) trsv_dot_kernel<T><<<dim3((unsigned)nchunks, NB / 4), 256, 0, s>>>(L, N, k, z, partials);
-    trsv_solve_kernel<T><<<1, 256, 0, s>>>(Tinv, N, k, nchunks, partials, r, n, z, quad);
+    if (h >= 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2, 1), 256, 0, s>>>(A, ld, k0, h, k, nbk, 1, 0);
+    launch_diag<T>(A, ld, (long)k * NB, Tinv, logdet, info, s, bt);
+    if (k + 1 < nbk) trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, 1), 256, 0, s>>>(A, Tinv, ld, k, 0);
   }
   return (int)hipGetLastError();
 }
@@ -522,8 +417,8 @@ struct EarlyLaunch {
 };
 
 template <typename T, int STEP>
-static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g1, EarlyLaunch* early, hipStream_t s,
-                        Batch bt) {
+static void trtri_level(const T* L, T* Tm, T* W, long N, long ld, int mblk, int g0, int g1, EarlyLaunch* early,
+                        hipStream_t s, Batch bt) {
   if (g1 <= g0) return;
   const int ng = g1 - g0;
   // fewer than ~two rounds (1024) of 128^2 tiles would leave the GPU waiting on the longest one: then use 64^2 tiles
@@ -542,17 +437,17 @@ static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g
   if (!queue) {
     const dim3 grid((unsigned)(m * m), (unsigned)ng, (unsigned)bt.B);
     if (small)
-      trtri_level_kernel<T, STEP, 64, false><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, nullptr, nullptr, bt.ws);
+      trtri_level_kernel<T, STEP, 64, false><<<grid, 256, 0, s>>>(L, Tm, W, ld, m, ntile, g0, ng, nullptr, nullptr, bt.ws);
     else
-      trtri_level_kernel<T, STEP, 128, false><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, nullptr, nullptr, bt.ws);
+      trtri_level_kernel<T, STEP, 128, false><<<grid, 256, 0, s>>>(L, Tm, W, ld, m, ntile, g0, ng, nullptr, nullptr, bt.ws);
     return;
   }
   int* ctr = early->ctr;
   early->ctr += 2;
   --early->pairs_left;
   const unsigned grid = (unsigned)early->wg_cap;
-  if (small) trtri_level_kernel<T, STEP, 64, true><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, ctr, early->resv, 0);
-  else trtri_level_kernel<T, STEP, 128, true><<<grid, 256, 0, s>>>(L, Tm, W, N, m, ntile, g0, ng, ctr, early->resv, 0);
+  if (small) trtri_level_kernel<T, STEP, 64, true><<<grid, 256, 0, s>>>(L, Tm, W, ld, m, ntile, g0, ng, ctr, early->resv, 0);
+  else trtri_level_kernel<T, STEP, 128, true><<<grid, 256, 0, s>>>(L, Tm, W, ld, m, ntile, g0, ng, ctr, early->resv, 0);
 }
 
 // Launch every step of the level recursion that the first `ready` block columns of L (and the diagonal blocks
@@ -565,7 +460,8 @@ static void trtri_level(const T* L, T* Tm, T* W, long N, int mblk, int g0, int g
 // the panel chain; `ctr` = nctr_pairs zeroed (queue, workers) int pairs, `reserve_cus` CUs are left to the chain.
 template <typename T>
 int trtri_advance(const T* L, long N, T* Tm, T* W, int ready, TrtriProgress* st, hipStream_t s, int wg_cap, int* ctr,
-                  int nctr_pairs, int reserve_cus, Batch bt) {
+                  int nctr_pairs, int reserve_cus, Batch bt, long ld) {
+  if (ld <= 0) ld = N;
   const int nbk = (int)(N / NB);
   if (ready > nbk) ready = nbk;
   EarlyLaunch el{wg_cap, ctr + 2 * st->pairs_used, nctr_pairs - st->pairs_used,
@@ -578,8 +474,8 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready, TrtriProgress* st,
     while (full < ngroups && (2 * m * (full + 1) < nbk ? 2 * m * (full + 1) : nbk) <= ready) ++full;
     int wcan = full;  // groups whose W-step can run
     if (wcan < ngroups && 2 * m * wcan + m <= ready) ++wcan;
-    trtri_level<T, 0>(L, Tm, W, N, m, st->wdone[lvl], wcan, early, s, bt);
-    trtri_level<T, 1>(L, Tm, W, N, m, st->gdone[lvl], full, early, s, bt);
+    trtri_level<T, 0>(L, Tm, W, N, ld, m, st->wdone[lvl], wcan, early, s, bt);
+    trtri_level<T, 1>(L, Tm, W, N, ld, m, st->gdone[lvl], full, early, s, bt);
     if (wcan > st->wdone[lvl]) st->wdone[lvl] = wcan;
     if (full > st->gdone[lvl]) st->gdone[lvl] = full;
   }
@@ -588,9 +484,10 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready, TrtriProgress* st,
 }
 
 template <typename T>
-int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long N, T* Tm, T* W, hipStream_t s, Batch bt) {
+int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long N, T* Tm, T* W, hipStream_t s, Batch bt,
+          long ld) {
   TrtriProgress st;
-  return trtri_advance<T>(L, N, Tm, W, (int)(N / NB), &st, s, 0, nullptr, 0, 0, bt);
+  return trtri_advance<T>(L, N, Tm, W, (int)(N / NB), &st, s, 0, nullptr, 0, 0, bt, ld);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -926,11 +823,9 @@ int sample_draws(const T* L, long M, const T* Z, long Q, const T* mean, int m, i
   template int symv_lower<T>(const T*, long, const T*, int, const T*, T*, T*, T*, hipStream_t);                  \
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \
                         const int*, hipEvent_t*, void (*)(void*, int), void*, Batch);                                                                                        \
-  template int potrf_group<T>(T*, long, T*, T*, int*, int, int, hipStream_t);                                     \
-  template int syrk_owned<T>(T*, long, int, int, int, int, int, int, hipStream_t);                                         \
-  template int trsv_lower<T>(const T*, const T*, long, const T*, int, T*, T*, T*, hipStream_t);                             \
-  template int trtri_advance<T>(const T*, long, T*, T*, int, TrtriProgress*, hipStream_t, int, int*, int, int, Batch);                   \
-  template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t, Batch);                                        \
+  template int potrf_group<T>(T*, long, int, T*, T*, int*, int, int, hipStream_t);                                \
+  template int trtri_advance<T>(const T*, long, T*, T*, int, TrtriProgress*, hipStream_t, int, int*, int, int, Batch, long);                   \
+  template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t, Batch, long);                                        \
   template int lauum<T>(const T*, long, T*, hipStream_t, Batch);                                                      \
   template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t, Batch);                           \
   template int finish<T>(const T*, const T*, long, int, T*, hipStream_t, Batch);                                      \

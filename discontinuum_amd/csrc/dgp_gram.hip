@@ -294,6 +294,111 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ Ks
   if (lane == 0) out[i] = acc;
 }
 
+// ------------------------------------------------------------------------------------------
+// Column-slab variants for ONE matrix distributed over several ranks (dgp_dist.hip).  A rank holds the block columns it
+// owns side by side: slab[r * Cl + lc], local 64-column tile lt <-> global tile gt = 2 gblock(lt / 2) + lt % 2.
+// gram_slab writes K^ for the owned columns from their diagonal block down (rows >= column block, 64 x 64 tiles).
+template <typename T, typename M>
+__global__ __launch_bounds__(256) void gram_slab_kernel(const T* __restrict__ Xt, long N, int n, const typename M::Pre pre,
+                                                        const T* __restrict__ noise, T* __restrict__ slab, long Cl, SlabMap sm) {
+  const int bi = blockIdx.x, lt = blockIdx.y;
+  const int bj = 2 * sm.gblock(lt >> 1) + (lt & 1);
+  if ((long)bj * 64 >= N || bi < bj) return;
+  __shared__ T sfi[M::NF][64], sfj[M::NF][64];
+  const int t = threadIdx.x;
+  if (t < 64) stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
+  else if (t < 128) stage_strip<T, M>(Xt, N, (long)bj * 64, pre, sfj, t - 64);
+  __syncthreads();
+  const int ty = t >> 4, tx = t & 15;
+  T fj[4][M::NF];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fj[b][c] = sfj[c][tx * 4 + b];
+  T dummy[M::NTHETA];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const long gi = (long)bi * 64 + ty * 4 + a;
+    T fi[M::NF];
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fi[c] = sfi[c][ty * 4 + a];
+    T out[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const long gj = (long)bj * 64 + tx * 4 + b;
+      T v = M::template pair<false>(fi, fj[b], pre, T(0), dummy);
+      if (gi >= n || gj >= n) v = (gi == gj) ? T(1) : T(0);  // identity pad
+      else if (gi == gj) v += noise[gi];
+      out[b] = v;
+    }
+    store4<T>(slab + gi * Cl + (long)lt * 64 + tx * 4, out);
+  }
+}
+
+// The rank's share of 1/2 sum_ij (S - alpha alpha^T)_ij dK_ij / dtheta: its slab of S = K^^-1 holds, for every owned
+// block column, the rows from the top down to the diagonal block (S_ij, i <= j).  Entries above the diagonal count
+// once with weight 1 (= 1/2 * 2), the diagonal with 1/2.  Tiles outside that region write zero partials.
+template <typename T, typename M>
+__global__ __launch_bounds__(256) void gram_grad_slab_kernel(const T* __restrict__ Xt, long N, int n, const typename M::Pre pre,
+                                                             const T* __restrict__ S, long Cl, SlabMap sm,
+                                                             const T* __restrict__ alpha, T* __restrict__ partials,
+                                                             T* __restrict__ dnoise_part) {
+  __shared__ T sfi[M::NF][64], sfj[M::NF][64], sai[64], saj[64];
+  __shared__ T red[4][M::NTHETA];
+  const int bi = blockIdx.x, lt = blockIdx.y;  // row tile, local column tile
+  const int bj = 2 * sm.gblock(lt >> 1) + (lt & 1);
+  const int t = threadIdx.x;
+  const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  if ((long)bj * 64 >= N || bi > bj) {
+    if (t < M::NTHETA) partials[blk * DGP_MAX_THETA + t] = T(0);
+    return;
+  }
+  if (t < 64) {
+    stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
+    sai[t] = alpha[(long)bi * 64 + t];
+  } else if (t < 128) {
+    stage_strip<T, M>(Xt, N, (long)bj * 64, pre, sfj, t - 64);
+    saj[t - 64] = alpha[(long)bj * 64 + t - 64];
+  }
+  __syncthreads();
+  const int ty = t >> 4, tx = t & 15;
+  T acc[M::NTHETA];
+#pragma unroll
+  for (int p = 0; p < M::NTHETA; ++p) acc[p] = T(0);
+#pragma unroll 1
+  for (int a = 0; a < 4; ++a) {
+    const long gi = (long)bi * 64 + ty * 4 + a;
+    T fi[M::NF];
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fi[c] = sfi[c][ty * 4 + a];
+    const T ai = sai[ty * 4 + a];
+    T sv[4];
+    load4<T>(S + gi * Cl + (long)lt * 64 + tx * 4, sv);
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
+      const int cj = tx * 4 + b;
+      const long gj = (long)bj * 64 + cj;
+      T fj[M::NF];
+#pragma unroll
+      for (int c = 0; c < M::NF; ++c) fj[c] = sfj[c][cj];
+      const T aj = saj[cj];
+      const T svb = b == 0 ? sv[0] : (b == 1 ? sv[1] : (b == 2 ? sv[2] : sv[3]));
+      T w = svb - ai * aj;
+      w = (gi > gj || gj >= n) ? T(0) : (gj == gi ? T(0.5) * w : w);
+      if (gi == gj && gi < n) dnoise_part[gi] = T(0.5) * (svb - ai * ai);
+      (void)M::template pair<true>(fi, fj, pre, w, acc);
+    }
+  }
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int p = 0; p < M::NTHETA; ++p) {
+    T v = wave_sum(acc[p]);
+    if (lane == 0) red[wv][p] = v;
+  }
+  __syncthreads();
+  if (t < M::NTHETA) partials[blk * DGP_MAX_THETA + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
+
 // deterministic second stage: one block, fixed summation order
 template <typename T>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ partials, long nblk, int nt,
@@ -415,6 +520,29 @@ int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, lo
 }
 
 template <typename T>
+int gram_slab(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* Aslab, long Cl,
+              SlabMap sm, hipStream_t s) {
+  if (model_ntheta(model, d) < 0) return -2;
+  dim3 grid((unsigned)(N / 64), (unsigned)(Cl / 64));
+  DGP_DISPATCH_MODEL(model, d, (gram_slab_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), noise, Aslab, Cl, sm)));
+  return (int)hipGetLastError();
+}
+
+long gram_grad_slab_partials(long N, long Cl) { return (N / 64) * (Cl / 64) * DGP_MAX_THETA; }
+
+template <typename T>
+int gram_grad_slab(int model, int d, const T* Xt, long N, int n, const double* theta, const T* Sslab, long Cl, SlabMap sm,
+                   const T* alpha, T* partials, T* dtheta, T* dnoise_part, hipStream_t s) {
+  const int nt = model_ntheta(model, d);
+  if (nt < 0) return -2;
+  dim3 grid((unsigned)(N / 64), (unsigned)(Cl / 64));
+  DGP_DISPATCH_MODEL(model, d, (gram_grad_slab_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xt, N, n, M::prepare(theta), Sslab, Cl, sm,
+                                                                                   alpha, partials, dnoise_part)));
+  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, (long)grid.x * grid.y, nt, dtheta, 0, 0, 0);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
 int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream_t s) {
   gemv_rows_kernel<T><<<(unsigned)((N + 3) / 4), 256, 0, s>>>(Ks, N, Mp, m, w, out);
   return (int)hipGetLastError();
@@ -429,7 +557,10 @@ int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream
                             long, void*, bool, void*);                                                         \
   template int mean_vjp_grad<T>(int, int, const T*, long, int, const T*, long, int, const double*, const T*, const T*, \
                                 const T*, T*, T*, hipStream_t);                                                    \
-  template int gemv_rows<T>(const T*, long, long, int, const T*, T*, hipStream_t);
+  template int gemv_rows<T>(const T*, long, long, int, const T*, T*, hipStream_t);                              \
+  template int gram_slab<T>(int, int, const T*, long, int, const double*, const T*, T*, long, SlabMap, hipStream_t); \
+  template int gram_grad_slab<T>(int, int, const T*, long, int, const double*, const T*, long, SlabMap, const T*, T*, T*, T*, \
+                                 hipStream_t);
 DGP_INST(double)
 DGP_INST(float)
 

@@ -61,7 +61,8 @@ struct TrtriProgress {
 };
 template <typename T>
 int trtri_advance(const T* L, long N, T* Tm, T* W, int ready_blocks, TrtriProgress* st, hipStream_t s, int wg_cap,
-                  int* ctr /* info + EARLY_CTR0, or null */, int nctr_pairs, int reserve_cus, Batch bt = Batch());
+                  int* ctr /* info + EARLY_CTR0, or null */, int nctr_pairs, int reserve_cus, Batch bt = Batch(),
+                  long ld = 0 /* leading dimension of L, Tm, W if not N */);
 // info[0] = potrf status; info[EARLY_CTR0 + 2i ..] = (tile queue, worker count) of the i-th early inverse launch
 #define EARLY_CTR0 4
 #define EARLY_CTR_PAIRS 126
@@ -69,7 +70,7 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready_blocks, TrtriProgre
 // per-device table of compute units kept free of early-inverse workgroups (null if unavailable)
 const unsigned char* reserved_cu_table(int nreserve, int* n_cu);
 template <typename T>
-int trtri(const T* L, const T* Dinv, long N, T* Tm, T* W, hipStream_t s, Batch bt = Batch());
+int trtri(const T* L, const T* Dinv, long N, T* Tm, T* W, hipStream_t s, Batch bt = Batch(), long ld = 0);
 template <typename T>
 int lauum(const T* Tm, long N, T* S, hipStream_t s, Batch bt = Batch());
 template <typename T>
@@ -83,16 +84,24 @@ template <typename T>
 int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* part, T* mean, T* var,
                 hipStream_t s);
 long solve_partials(long N);
-// ---- one matrix over several GPUs (block-cyclic groups of W panels; see dgp_chol.hip) ----------
+// ---- one matrix over several GPUs (dgp_dist.hip): the panel chain of W block columns on a slab-addressed matrix
 template <typename T>
-int potrf_group(T* A, long N, T* Tinv, T* logdet, int* info, int k0, int W, hipStream_t s);
+int potrf_group(T* A, long ld, int nbk, T* Tinv, T* logdet, int* info, int k0, int W, hipStream_t s);
+// Block-cyclic column ownership: groups of W 128-wide panels, group g on rank g % world; a rank keeps its groups side
+// by side in a slab of Cl columns (local column block lb <-> global block column gblock(lb)).
+struct SlabMap {
+  int W, world, rank;
+  __host__ __device__ int gblock(int lb) const { return ((lb / W) * world + rank) * W + lb % W; }
+};
 template <typename T>
-int syrk_owned(T* A, long N, int k0, int W, int rank, int world, int jb0, int jb1 /* owned block columns in [jb0, jb1) */,
-               hipStream_t s);
+int gram_slab(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* Aslab, long Cl,
+              SlabMap sm, hipStream_t s);
+// partial gradient over the tiles of K^^-1 this rank holds (rows <= columns of its own block columns) and
+// 1/2 (diag K^^-1 - alpha^2) for its own columns (dnoise_part: N entries, others untouched)
 template <typename T>
-int trsv_lower(const T* L, const T* Tinv /* its diagonal blocks */, long N, const T* r, int n, T* z, T* partials,
-               T* quad, hipStream_t s);
-long trsv_partials(long N);
+int gram_grad_slab(int model, int d, const T* Xt, long N, int n, const double* theta, const T* Sslab, long Cl, SlabMap sm,
+                   const T* alpha, T* partials, T* dtheta, T* dnoise_part, hipStream_t s);
+long gram_grad_slab_partials(long N, long Cl);
 template <typename T>
 int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T* partials, T* dnoise, hipStream_t s);
 // cov (M x M) = Kss - V^T V, lower tiles; Kss already holds K(Xs, Xs) (identity pad)

@@ -80,7 +80,7 @@ size_t dgp_plan_workspace_bytes(const dgp_plan* plan);
  * r / noise / dr / dnoise [batch][n], out[batch][DGP_OUT_LEN].  dgp_predict and dgp_predict_mean also accept batched
  * plans (every site predicts at its own m points: Xs[batch][m][d], theta[batch][ntheta] -> mean / var [batch][m]; the
  * sites' launches follow each other on the stream and share the one workspace); the other inference entry points
- * (dgp_posterior_cov, dgp_mean_vjp, dgp_cross_gram, the dgp_dist_* family) need batch == 1. */
+ * (dgp_posterior_cov, dgp_mean_vjp, dgp_cross_gram) need batch == 1. */
 int dgp_plan_set_batch(dgp_plan* plan, int batch);
 int dgp_plan_batch(const dgp_plan* plan);
 /* Ragged batches (after dgp_plan_set_workspace, before dgp_set_inputs): site b has sizes[b] <= n observations; it
@@ -180,25 +180,55 @@ int dgp_mean_vjp(dgp_plan* plan, const double* theta_host, const void* Xs_dev, i
 int dgp_plan_set_timing(dgp_plan* plan, int enabled);
 int dgp_plan_get_timing(dgp_plan* plan, double* ms_out);
 
-/* ---- single stages on the plan buffers, for parity tests and per-kernel profiling ---- */
-/* ONE matrix distributed over `world` GPUs (BASELINE config 5; nothing in the reference).  Every rank owns a full-size
- * plan; block columns are dealt to the ranks in groups of `nblocks` 128-wide panels, group g to rank g % world.  Per
- * group: the owner calls dgp_dist_factor_group, the host side broadcasts rows >= 128 first_block of the group's
- * columns of DGP_BUF_A (and the inverses of their diagonal blocks, DGP_BUF_T) to the other ranks (torch.distributed /
- * RCCL), then EVERY rank calls dgp_dist_update, which
- * applies the group's panels to the block columns it owns right of the group.  dgp_dist_begin zeroes the local
- * log-determinant / info (DGP_BUF_SCAL[0], DGP_BUF_INFO) after dgp_stage_gram; after the last group every rank holds
- * all of L, and dgp_dist_finish(r, sum of the ranks' log-determinants, max of their infos) solves L z = r by block
- * rows and writes out[DGP_OUT_NLL / QUAD / LOGDET / INFO].  discontinuum_amd/dist_chol.py drives this. */
-int dgp_dist_begin(dgp_plan* plan, void* stream);
-int dgp_dist_factor_group(dgp_plan* plan, int first_block, int nblocks, void* stream);
-/* col_begin / col_end restrict the update to the owned block columns in [col_begin, col_end) (col_end <= 0: to the
- * end): the owner of the next group brings that group up to date first, factors it and starts its broadcast while
- * the rest of the update is still running (lookahead). */
-int dgp_dist_update(dgp_plan* plan, int first_block, int nblocks, int rank, int world, int col_begin, int col_end,
-                    void* stream);
-int dgp_dist_finish(dgp_plan* plan, const void* r_dev, double logdet_total, int info_total, void* out_dev, void* stream);
+/* ---- ONE matrix distributed over `world` GPUs (BASELINE config 5; nothing in the reference corresponds) ----------
+ * 1-D block-cyclic by column groups of `group_panels` 128-wide panels, group g on rank g % world.  A rank holds ONLY its
+ * own groups -- three column slabs (K^ -> L, L^-1, K^^-1) of N x (its groups x 128 group_panels) elements, N =
+ * dgp_dist_padded_n() -- plus whatever panel buffers the caller allocates for the payloads in flight
+ * (dgp_dist_panel_elems(group) elements).  The caller moves the payloads (torch.distributed broadcast = RCCL over xGMI;
+ * discontinuum_amd/dist_chol.py) and sums the O(n) vectors; all O(n^2) / O(n^3) work is in these entry points.
+ *
+ *   dgp_dist_gram                         every rank: its columns of K^ (the inputs are replicated)
+ *   for g = 0 .. groups-1:   dgp_dist_factor(g, panel)        owner: panel chain, diagonal-block inverse, pack
+ *                            <broadcast panel from rank g % world>
+ *                            dgp_dist_update(g, panel, cb, ce) every rank: its block columns in [cb, ce) right of g
+ *                                                              (ce <= 0: to the end; the owner of g + 1 brings that group
+ *                                                              up to date first and factors it while the rest runs)
+ *                            dgp_dist_invert(g, panel)         every rank: its columns of L^-1 advance by group g
+ *   dgp_dist_status -> (local log-determinant, local info)     sum / max over the ranks
+ *   dgp_dist_solve_partial(r) -> z_part (N)                    sum over the ranks: z = L^-1 r ;  r^T K^^-1 r = z^T z
+ *   dgp_dist_alpha_partial(z) -> alpha_part (N)                sum over the ranks: alpha = K^^-1 r
+ *   for g = 0 .. groups-1:   dgp_dist_pack_inverse(g, panel)  owner: its columns of L^-1 from the diagonal down
+ *                            <broadcast>
+ *                            dgp_dist_product(g, panel)        every rank: K^^-1 [group g rows, its columns >= g]
+ *   dgp_dist_grad_partial(theta, alpha) -> dtheta_part (DGP_OUT_LEN, first ntheta valid), dnoise_part (N, zeros outside
+ *                            the rank's columns)               sum over the ranks: dNLL/dtheta, 1/2 (diag K^^-1 - alpha^2)
+ * Together: the NLL and ALL gradients of one fit step (engines/gpytorch.py:350-384) with N^3 / world flops per rank. */
+typedef struct dgp_dist dgp_dist;
+const char* dgp_dist_last_error(void);
+int dgp_dist_create(int model, int dtype, int64_t n, int d, int rank, int world, int group_panels, dgp_dist** out);
+int dgp_dist_destroy(dgp_dist* h);
+int64_t dgp_dist_padded_n(const dgp_dist* h);     /* round_up(n, 128 group_panels) */
+int dgp_dist_groups(const dgp_dist* h);
+int64_t dgp_dist_slab_columns(const dgp_dist* h); /* columns of each of the rank's three slabs */
+size_t dgp_dist_workspace_bytes(const dgp_dist* h);
+size_t dgp_dist_panel_elems(const dgp_dist* h, int group);
+int dgp_dist_set_workspace(dgp_dist* h, void* dev_ptr, size_t bytes);
+int dgp_dist_set_inputs(dgp_dist* h, const void* X_dev, void* stream);
+int dgp_dist_gram(dgp_dist* h, const double* theta_host, const void* noise_dev, void* stream);
+int dgp_dist_factor(dgp_dist* h, int group, void* panel_dev, void* stream);
+int dgp_dist_update(dgp_dist* h, int group, const void* panel_dev, int col_begin, int col_end, void* stream);
+int dgp_dist_invert(dgp_dist* h, int group, const void* panel_dev, void* stream);
+int dgp_dist_status(dgp_dist* h, void* stat_dev /* 2 elements */, void* stream);
+int dgp_dist_solve_partial(dgp_dist* h, const void* r_dev, void* z_part_dev, void* stream);
+int dgp_dist_alpha_partial(dgp_dist* h, const void* z_dev, void* alpha_part_dev, void* stream);
+int dgp_dist_pack_inverse(dgp_dist* h, int group, void* panel_dev, void* stream);
+int dgp_dist_product(dgp_dist* h, int group, const void* panel_dev, void* stream);
+int dgp_dist_grad_partial(dgp_dist* h, const double* theta_host, const void* alpha_dev, void* dtheta_part_dev,
+                          void* dnoise_part_dev, void* stream);
+/* the rank's slab `which` = DGP_BUF_A / DGP_BUF_T / DGP_BUF_S (tests) */
+int dgp_dist_slab(const dgp_dist* h, int which, void** dev_ptr);
 
+/* ---- single stages on the plan buffers, for parity tests and per-kernel profiling ---- */
 int dgp_stage_gram(dgp_plan* plan, const double* theta_host, const void* noise_dev, void* stream);
 int dgp_stage_potrf(dgp_plan* plan, void* stream);  /* A: K^ -> L ; T diag blocks <- L_kk^-1 */
 int dgp_stage_trtri(dgp_plan* plan, void* stream);  /* T <- L^-1 */

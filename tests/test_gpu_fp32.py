@@ -1,0 +1,94 @@
+"""float32 as a first-class path (it is the reference's dtype: src/discontinuum/engines/gpytorch.py:221-222).
+
+The fp32 HIP path against the fp64 oracle at n = 4096 for both models (the dense CPU oracle takes seconds there), with
+the tolerance tied to what fp32 can deliver on THIS matrix: the oracle measures cond(K^) and the test requires
+
+    alpha:      ||alpha32 - alpha64|| / ||alpha64||  <=  4 cond(K^) eps32        (backward-stable solve)
+    NLL:        |NLL32 - NLL64| / |NLL64|            <=  1e-4 max(1, n / 1024)    
+    gradients:  max |g32 - g64| / max |g64|          <=  1e-2                     
+    posterior:  mean abs <= 1e-3, variance abs <= 1e-3                            
+
+and records what it measured (``gpurun_out/fp32_parity.jsonl`` when that directory exists; DESIGN.md section 5 quotes
+it).  Size-independent checks at the full sizes of BASELINE configs 3 and 5 live in tests/test_gpu_fullsize.py.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import gp_oracle as orc
+from tests.test_gpu_stages import make_case, plan_for
+
+pytestmark = pytest.mark.gpu
+
+EPS32 = 2.0 ** -24
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(**row):
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "fp32_parity.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
+
+
+@pytest.mark.parametrize("model,d,n", [("loadest", 3, 4096), ("rating", 2, 4096), ("loadest", 2, 1500), ("rating", 2, 1500)])
+def test_fp32_fit_step_and_posterior_against_the_fp64_oracle(model, d, n, gpu_device):
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=7, perturb=0.1)
+    Xs, *_ = make_case(model, d, 300, seed=8)
+    val, g_theta, g_r, g_noise = orc.nll_data_and_grads(model, X, r, noise, theta)
+    Khat = orc.GRAMS[model](X, X, theta) + torch.diag(noise)
+    ev = torch.linalg.eigvalsh(Khat)
+    cond = (ev[-1] / ev[0]).item()
+    mu_ref, var_ref = orc.posterior(model, X, r, noise, theta, Xs)
+    p = plan_for(model, d, n, X, torch.float32, dev)
+    out, dr, dnoise = p.fit_step(theta, r.to(dev, torch.float32), noise.to(dev, torch.float32))
+    out = out.cpu().double()
+    assert out[_lib.OUT_INFO] == 0
+    P = theta.numel()
+    e_nll = abs(out[_lib.OUT_NLL] - val).item() / abs(val).item()
+    e_grad = ((out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + P] - g_theta).abs().max() / g_theta.abs().max()).item()
+    e_alpha = (torch.linalg.norm(dr.cpu().double() - g_r) / torch.linalg.norm(g_r)).item()
+    e_dnoise = ((dnoise.cpu().double() - g_noise).abs().max() / g_noise.abs().max()).item()
+    mean, var = p.predict(theta, Xs.to(dev, torch.float32))
+    e_mean = (mean.cpu().double() - mu_ref).abs().max().item()
+    e_var = (var.cpu().double() - var_ref).abs().max().item()
+    _record(test="fp32_vs_fp64_oracle", model=model, d=d, n=n, cond=cond, nll_rel=e_nll, grad_rel=e_grad, alpha_rel=e_alpha,
+            dnoise_rel=e_dnoise, mean_abs=e_mean, var_abs=e_var, alpha_bound=4 * cond * EPS32)
+    assert e_nll <= 1e-4 * max(1.0, n / 1024), e_nll
+    assert e_grad <= 1e-2, e_grad
+    assert e_alpha <= 4 * cond * EPS32, (e_alpha, cond)
+    assert e_dnoise <= 1e-2 + 4 * cond * EPS32, e_dnoise
+    assert e_mean <= 1e-3 and e_var <= 1e-3, (e_mean, e_var)
+
+
+@pytest.mark.parametrize("model,d", [("loadest", 3), ("rating", 2)])
+def test_fp32_batched_and_single_plans_agree_at_n4096(model, d, gpu_device):
+    """The same fp32 kernels under the batched schedule (groups of four panels) and the single-site schedule (pairs,
+    early inverse): NLL to 2e-5, alpha to 4 cond eps32 of each other at n = 4096."""
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev, n, B = gpu_device, 4096, 4
+    cases = [make_case(model, d, n, seed=90 + b, perturb=0.1) for b in range(B)]
+    X = torch.stack([c[0] for c in cases]).float().to(dev).contiguous()
+    r = torch.stack([c[1] for c in cases]).float().to(dev).contiguous()
+    noise = torch.stack([c[2] for c in cases]).float().to(dev).contiguous()
+    theta = torch.stack([c[3] for c in cases])
+    pb = GPPlan(model, n, d, dtype=torch.float32, device=dev, lookahead=1, batch=B)
+    pb.set_inputs(X)
+    out, dr, _ = pb.fit_step(theta, r, noise)
+    p1 = GPPlan(model, n, d, dtype=torch.float32, device=dev)
+    for b in (0, B - 1):
+        p1.set_inputs(X[b].contiguous())
+        o1, a1, _ = p1.fit_step(theta[b], r[b].contiguous(), noise[b].contiguous())
+        assert int(out[b, _lib.OUT_INFO]) == 0 and int(o1[_lib.OUT_INFO]) == 0
+        e_nll = (abs(out[b, 0] - o1[0]) / abs(o1[0])).item()
+        e_alpha = (torch.linalg.norm((dr[b] - a1).double()) / torch.linalg.norm(a1.double())).item()
+        _record(test="fp32_batched_vs_single", model=model, n=n, site=b, nll_rel=e_nll, alpha_rel=e_alpha)
+        assert e_nll <= 2e-5, e_nll
+        assert e_alpha <= 2e-2, e_alpha
