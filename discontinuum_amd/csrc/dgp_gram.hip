@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt,
   int bi, bj;
   tri_decode(blockIdx.x, bi, bj);
   const int t = threadIdx.x;
+  exp_table_init<T>();
   if (t < 64) stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
   else if (t < 128) stage_strip<T, M>(Xt, N, (long)bj * 64, pre, sfj, t - 64);
   __syncthreads();
@@ -94,6 +95,9 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt,
 #pragma unroll
     for (int c = 0; c < M::NF; ++c) fj[b][c] = sfj[c][tx * 4 + b];
   T dummy[M::NTHETA];
+  // interior tiles (strictly below the diagonal, no padding rows or columns) skip the per-entry pad / noise selects:
+  // a workgroup-uniform branch that almost every tile takes
+  const bool interior = bi != bj && (long)bi * 64 + 64 <= n;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const long gi = (long)bi * 64 + ty * 4 + a;
@@ -101,13 +105,18 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt,
 #pragma unroll
     for (int c = 0; c < M::NF; ++c) fi[c] = sfi[c][ty * 4 + a];
     T out[4];
+    if (interior) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const long gj = (long)bj * 64 + tx * 4 + b;
-      T v = M::template pair<false>(fi, fj[b], pre, T(0), dummy);
-      if (gi >= n || gj >= n) v = (gi == gj) ? T(1) : T(0);  // identity pad
-      else if (gi == gj) v += noise[gi];
-      out[b] = v;
+      for (int b = 0; b < 4; ++b) out[b] = M::template pair<false>(fi, fj[b], pre, T(0), dummy);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const long gj = (long)bj * 64 + tx * 4 + b;
+        T v = M::template pair<false>(fi, fj[b], pre, T(0), dummy);
+        if (gi >= n || gj >= n) v = (gi == gj) ? T(1) : T(0);  // identity pad
+        else if (gi == gj) v += noise[gi];
+        out[b] = v;
+      }
     }
     store4<T>(K + gi * N + (long)bj * 64 + tx * 4, out);
   }
@@ -120,6 +129,7 @@ __global__ __launch_bounds__(256) void gram_cross_kernel(const T* __restrict__ X
   __shared__ T sfi[M::NF][64], sfj[M::NF][64];
   const int bi = blockIdx.y, bj = blockIdx.x;
   const int t = threadIdx.x;
+  exp_table_init<T>();
   if (t < 64) stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
   else if (t < 128) stage_strip<T, M>(Xst, Mp, (long)bj * 64, pre, sfj, t - 64);
   __syncthreads();
@@ -152,6 +162,8 @@ __global__ __launch_bounds__(256) void gram_cross_kernel(const T* __restrict__ X
 template <typename T, typename M>
 __global__ __launch_bounds__(256) void gram_diag_kernel(const T* __restrict__ Xst, long Mp, int m, const typename M::Pre pre,
                                                         T* __restrict__ kss) {
+  exp_table_init<T>();
+  __syncthreads();
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= Mp) return;
   T x[M::NX], f[M::NF], dummy[M::NTHETA];
@@ -181,6 +193,7 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt
   int bi, bj;
   tri_decode(blockIdx.x, bi, bj);
   const int t = threadIdx.x;
+  exp_table_init<T>();
   if (t < 64) {
     stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
     sai[t] = alpha[(long)bi * 64 + t];
@@ -242,6 +255,7 @@ __global__ __launch_bounds__(256) void gram_cross_grad_kernel(const T* __restric
   __shared__ T red[4][M::NTHETA];
   const int bi = blockIdx.y, bj = blockIdx.x;
   const int t = threadIdx.x;
+  exp_table_init<T>();
   if (t < 64) {
     stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
     sai[t] = alpha[(long)bi * 64 + t];
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(256) void gram_slab_kernel(const T* __restrict__ Xt
   if ((long)bj * 64 >= N || bi < bj) return;
   __shared__ T sfi[M::NF][64], sfj[M::NF][64];
   const int t = threadIdx.x;
+  exp_table_init<T>();
   if (t < 64) stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
   else if (t < 128) stage_strip<T, M>(Xt, N, (long)bj * 64, pre, sfj, t - 64);
   __syncthreads();
@@ -353,6 +368,7 @@ __global__ __launch_bounds__(256) void gram_grad_slab_kernel(const T* __restrict
     if (t < M::NTHETA) partials[blk * DGP_MAX_THETA + t] = T(0);
     return;
   }
+  exp_table_init<T>();
   if (t < 64) {
     stage_strip<T, M>(Xt, N, (long)bi * 64, pre, sfi, t);
     sai[t] = alpha[(long)bi * 64 + t];

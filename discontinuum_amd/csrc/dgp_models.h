@@ -26,27 +26,46 @@ namespace dgp {
 // (positive or non-finite arguments, denormal results) -- the library versions spend a third of their instructions on
 // those cases.  The periodic term needs no per-pair sine at all: sin and cos of pi t / p are per-POINT features
 // (evaluated in double once per 64 x 64 tile strip) and the pair uses the angle-difference identities.
+// e^x for x <= 0 in double: x = n ln2 / 64 + r with |r| <= ln2 / 128, e^x = 2^(n >> 6) * 2^((n & 63) / 64) * e^r.  The 64
+// table entries 2^(j/64) (correctly rounded) sit in LDS -- a per-lane gather, ds_read_b64 -- and e^r is a degree-5
+// polynomial (truncation r^6 / 720 < 3.5e-17 relative).  13 VALU + 1 LDS instruction against 21 VALU for the table-free
+// version (same range reduction by ln2, degree-13 polynomial) this replaces.  Every kernel that evaluates a covariance
+// in double calls exp_table_init() before the barrier that precedes its first pair().
+__constant__ double dgp_exp_tab_c[64] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+__shared__ double dgp_exp_tab[64];
+template <typename T>
+__device__ __forceinline__ void exp_table_init() {
+  if (sizeof(T) == 8 && threadIdx.x < 64) dgp_exp_tab[threadIdx.x] = dgp_exp_tab_c[threadIdx.x];
+}
 __device__ __forceinline__ double exp_nonpos(double x) {
-  // e^x for x <= 0: x = n ln2 + r, |r| <= ln2 / 2, degree-13 Taylor polynomial (truncation 4e-18 relative)
   x = x < -708.0 ? -708.0 : x;  // below e^-708 = 3e-308 the result only matters as "zero"; a NaN stays a NaN
-  const double n = __builtin_rint(x * 1.44269504088896340736);
-  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
-  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
-  double p = 1.0 / 6227020800.0;
-  p = __builtin_fma(p, r, 1.0 / 479001600.0);
-  p = __builtin_fma(p, r, 1.0 / 39916800.0);
-  p = __builtin_fma(p, r, 1.0 / 3628800.0);
-  p = __builtin_fma(p, r, 1.0 / 362880.0);
-  p = __builtin_fma(p, r, 1.0 / 40320.0);
-  p = __builtin_fma(p, r, 1.0 / 5040.0);
-  p = __builtin_fma(p, r, 1.0 / 720.0);
-  p = __builtin_fma(p, r, 1.0 / 120.0);
+  const double n = __builtin_rint(x * 92.33248261689366);
+  double r = __builtin_fma(n, -0.010830424695086549, x);  // ln2 / 64 in two parts: n * hi is exact for |n| < 2^20
+  r = __builtin_fma(n, -1.162596423439437e-12, r);
+  const int ni = (int)n;
+  double p = 1.0 / 120.0;
   p = __builtin_fma(p, r, 1.0 / 24.0);
   p = __builtin_fma(p, r, 1.0 / 6.0);
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  return ldexp(p, (int)n);
+  return ldexp(dgp_exp_tab[ni & 63] * p, ni >> 6);
 }
 __device__ __forceinline__ float exp_nonpos(float x) { return exp(x); }
 

@@ -287,4 +287,77 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     return last_obj
 
 
-__all__ = ["fit_many"]
+def predict_many(models, covariates_list):
+    """``models[i].predict(covariates_list[i])`` for many fitted sites through ONE batched device plan: one batched
+    factorisation (``dgp_factorize`` with gridDim.z = sites) and one ``dgp_predict`` over all sites, instead of a plan, a
+    factorisation and a prediction per site (the reference fans predictions out per site / per date:
+    ``examples/nwqn-loadest-example/nwqn-loadest-example.py:38-125``, ``src/rating_gp/plot.py:259-285``).
+    Returns ``[(target, se), ...]`` in the original data space, like ``MarginalHIP.predict``.  Sites may differ in the
+    number of observations and of prediction points (ragged batch; shorter sites are padded)."""
+    if len(models) != len(covariates_list) or not models:
+        raise ValueError("predict_many needs one covariates object per model")
+    for m in models:
+        if not m.is_fitted:
+            raise RuntimeError("The model hasn't been fitted yet, call .fit().")
+    B = len(models)
+    dtype, device = models[0].dtype, torch.device(models[0].device)
+    xs, ys, xnew, thetas, means, noises, names = [], [], [], [], [], [], set()
+    with torch.no_grad():
+        for m, cov in zip(models, covariates_list):
+            m.model.eval()
+            m.likelihood.eval()
+            x = torch.tensor(m.dm.X, dtype=dtype)
+            y = torch.tensor(m.dm.y, dtype=dtype)
+            xn = torch.tensor(m.dm.Xnew(cov), dtype=dtype)
+            if hasattr(m.model, "prepare_eval"):
+                m.model.prepare_eval(x, xn)  # data-dependent clamps see [X; X*] (SURVEY A.8)
+            name, theta_fn = lower(m.model.covar_module, x.shape[1])
+            names.add((name, x.shape[1]))
+            xs.append(x)
+            ys.append(y)
+            xnew.append(xn)
+            thetas.append(theta_fn().detach().to(torch.float64))
+            means.append(m.model.prior_mean(x).detach().to(dtype))
+            noises.append(m.likelihood.train_noise(torch.device("cpu"), dtype).detach().reshape(-1))
+    if len(names) != 1:
+        raise ValueError("predict_many needs sites of one model family and one input dimension")
+    (name, d), = names
+    sizes, msizes = [x.shape[0] for x in xs], [x.shape[0] for x in xnew]
+    n, mmax = max(sizes), max(msizes)
+    plan = GPPlan(name, n, d, dtype=dtype, device=device, lookahead=1 if B > 1 else 2, batch=B)
+    if B > 1:
+        plan.set_site_sizes(sizes)
+
+    def slots(ts, width, fill=0.0):
+        out = torch.full((B, width) + tuple(ts[0].shape[1:]), fill, dtype=dtype)
+        for b, t in enumerate(ts):
+            out[b, : t.shape[0]] = t
+        return out
+
+    X = slots(xs, n).to(device).contiguous()
+    R = slots([y - mu for y, mu in zip(ys, means)], n).to(device).contiguous()
+    Nz = slots(noises, n, 1.0).to(device).contiguous()
+    Xs = torch.stack([torch.cat([xn, xn[-1:].expand(mmax - xn.shape[0], -1)]) for xn in xnew]).to(device).contiguous()
+    theta = torch.stack(thetas)
+    single = B == 1
+    plan.set_inputs(X[0].contiguous() if single else X)
+    out = plan.factorize(theta[0] if single else theta, R[0].contiguous() if single else R, Nz[0].contiguous() if single else Nz)
+    info = out.reshape(B, -1)[:, _lib.OUT_INFO].cpu()
+    if bool((info != 0).any()):
+        bad = int(torch.nonzero(info)[0])
+        raise RuntimeError(f"site {bad}: matrix not positive definite (Cholesky pivot {int(info[bad])})")
+    kmean, kvar = plan.predict(theta[0] if single else theta, Xs[0].contiguous() if single else Xs)
+    kmean, kvar = kmean.reshape(B, mmax).cpu(), kvar.reshape(B, mmax).cpu()
+    results = []
+    with torch.no_grad():
+        for b, (m, cov) in enumerate(zip(models, covariates_list)):
+            mb = msizes[b]
+            mu = kmean[b, :mb] + m.model.prior_mean(xnew[b]).to(dtype)
+            var = kvar[b, :mb] + m.likelihood.predictive_noise(mb, torch.device("cpu"), dtype)
+            target = m.dm.y_t(mu.numpy()).assign_coords(cov.coords)
+            se = m.dm.error_pipeline.inverse_transform(var.numpy()).assign_coords(cov.coords)
+            results.append((target, se))
+    return results
+
+
+__all__ = ["fit_many", "predict_many"]

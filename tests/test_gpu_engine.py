@@ -264,3 +264,31 @@ def test_fit_many_with_a_single_site_uses_the_unbatched_plan(gpu_device):
     pa = torch.cat([p.detach().reshape(-1) for p in pair[0].model.parameters()])
     pb = torch.cat([p.detach().reshape(-1) for p in alone[0].model.parameters()])
     assert (pa - pb).abs().max() < 1e-6, (pa - pb).abs().max()
+
+
+@pytest.mark.parametrize("family", ["loadest", "rating"])
+def test_predict_many_matches_per_site_predict(family, gpu_device):
+    """``predict_many``: one batched factorisation + one batched ``dgp_predict`` for all sites (ragged in n and in m)
+    gives what each site's own ``predict`` gives (its own plan, its own factorisation): rel 1e-9."""
+    from discontinuum_amd.multisite_fit import fit_many, predict_many
+
+    if family == "loadest":
+        from discontinuum_amd.loadest_gp import LoadestGP as Model
+
+        data = [loadest_dataset(k, seed=800 + i) for i, k in enumerate([90, 64, 130])]
+        new = [loadest_dataset(k, seed=850 + i)[0] for i, k in enumerate([40, 75, 33])]
+    else:
+        from discontinuum_amd.rating_gp import RatingGP as Model
+
+        data = [rating_dataset(k, seed=800 + i) for i, k in enumerate([70, 48, 96])]
+        new = [rating_dataset(k, seed=850 + i)[0] for i, k in enumerate([30, 51, 18])]
+    torch.manual_seed(4)
+    models = [Model() for _ in data]
+    fit_many(models, data, iterations=15)
+    both = predict_many(models, new)
+    alone = predict_many(models[:1], new[:1])
+    for m, cov, (t_b, se_b) in zip(models, new, both):
+        t_s, se_s = m.predict(cov)
+        assert np.allclose(t_b.values, t_s.values, rtol=1e-9) and np.allclose(se_b.values, se_s.values, rtol=1e-9)
+        assert list(t_b.coords) == list(t_s.coords)
+    assert np.allclose(alone[0][0].values, both[0][0].values, rtol=1e-9)
