@@ -147,8 +147,8 @@ def stage_report(plan, S, dtype_name, level, lib):
         "trtri_level_kernel": {"flops": S * N ** 3 / 3.0, "ms": ms[lib.TIME_TRTRI], "launches": None},
         "lauum_kernel": {"flops": S * N ** 3 / 3.0, "ms": ms[lib.TIME_LAUUM], "launches": 1},
     }
-    if level == 2:  # most of the inverse ran under the factorisation: its stage time is only the remainder
-        stages["trtri_level_kernel"]["flops"] = None
+    if level == 2 and S == 1 and 16 <= N // 128 <= 80:  # the early inverse applies (dgp_api.hip::early_applies): most of
+        stages["trtri_level_kernel"]["flops"] = None     # it ran under the factorisation, the stage time is the remainder
     for v in stages.values():
         v["tflops"] = v["flops"] / (v["ms"] * 1e-3) / 1e12 if (v["flops"] and v["ms"] > 0) else None
     # the dominant KERNEL: trtri is a stage of a dozen launches of several kernel instantiations, none of which

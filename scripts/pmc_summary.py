@@ -5,10 +5,12 @@ FETCH_SIZE reports exactly half of the bytes of coalesced streaming reads -- cal
 known byte count (trmv_n reads N(N+128)/2*8 B of the lower triangle, gram_grad reads N(N+64)/2*8 B):
 both report 0.50x -- so fetch bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is exact (gram_sym writes
 N(N+64)/2*8 B = 270.7 MB; counter 270.5 MB).
-usage: python scripts/pmc_summary.py <fetch_dir> <write_dir> <out.json> [steps_in_run [sites_per_launch]]
+usage: python scripts/pmc_summary.py <fetch_dir> <write_dir> <out.json> [steps_in_run [sites_per_launch [commit]]]
+The output records bench.source_hash() of the tree it is run in: bench.py emits `traffic` only while that still matches.
 ("fit" in the output = one step of the batched plan, i.e. one launch sequence carrying sites_per_launch sites)
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 def per_kernel(d, name):
     rows = list(csv.DictReader(open(glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0])))
@@ -24,7 +26,13 @@ def per_kernel(d, name):
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 fits = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 out = {"_note": "bytes; fetch = 2 * FETCH_SIZE KiB (gfx950 half-count correction, calibrated), write = WRITE_SIZE KiB",
-       "fits_in_run": fits, "sites_per_launch": int(sys.argv[5]) if len(sys.argv) > 5 else None, "kernels": {}}
+       "fits_in_run": fits, "sites_per_launch": int(sys.argv[5]) if len(sys.argv) > 5 else None,
+       "commit": sys.argv[6] if len(sys.argv) > 6 else None, "kernels": {}}
+try:
+    import bench
+    out["source_hash"] = bench.source_hash()
+except Exception as e:  # noqa: BLE001
+    out["source_hash"] = None
 for k in sorted(set(fetch) | set(write)):
     nf, vf = fetch.get(k, [0, 0.0]); nw, vw = write.get(k, [0, 0.0])
     n = max(nf, nw)
