@@ -38,6 +38,7 @@ SIGNATURES = {
     "dgp_version": (_i, []),
     "dgp_last_error": (C.c_char_p, []),
     "dgp_model_ntheta": (_i, [_i, _i]),
+    "dgp_composite_define": (_i, [C.POINTER(_i), _i, C.POINTER(_i)]),
     "dgp_padded_n": (_i64, [_i64]),
     "dgp_plan_create": (_i, [_i, _i, _i64, _i, C.POINTER(_vp)]),
     "dgp_plan_destroy": (_i, [_vp]),

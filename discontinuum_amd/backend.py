@@ -14,6 +14,16 @@ import torch
 from . import _lib
 
 MODELS = {"loadest": _lib.MODEL_LOADEST, "rating": _lib.MODEL_RATING}
+
+
+def model_id(model: str) -> int:
+    """``"loadest"`` / ``"rating"`` (the fused evaluators) or ``"composite:<id>"`` (a generic model registered through
+    ``dgp_composite_define``; ``gp.lowering.lower`` returns such names)."""
+    if model in MODELS:
+        return MODELS[model]
+    if isinstance(model, str) and model.startswith("composite:") and model[10:].isdigit():
+        return int(model[10:])
+    raise ValueError(f"unknown model {model!r}; expected one of {sorted(MODELS)} or 'composite:<id>'")
 _DTYPES = {torch.float64: _lib.F64, torch.float32: _lib.F32}
 
 
@@ -43,8 +53,7 @@ class GPPlan:
         ``batch`` > 1: the plan carries that many independent sites in lockstep (one launch per kernel for all of
         them); ``set_inputs`` / ``fit_step`` / ``factorize`` then take batch-major arrays -- X (batch, n, d),
         theta (batch, ntheta), r / noise (batch, n) -- and return (batch, 32), (batch, n), (batch, n)."""
-        if model not in MODELS:
-            raise ValueError(f"unknown model {model!r}; expected one of {sorted(MODELS)}")
+        mid = model_id(model)
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.lib = _lib.load()
@@ -52,12 +61,12 @@ class GPPlan:
             raise RuntimeError("discontinuum_amd requires a ROCm GPU (MI355X); there is no CPU fallback")
         self.model, self.n, self.d, self.dtype = model, int(n), int(d), dtype
         self.device = torch.device(device)
-        self.ntheta = self.lib.dgp_model_ntheta(MODELS[model], self.d)
+        self.ntheta = self.lib.dgp_model_ntheta(mid, self.d)
         if self.ntheta < 0:
             raise ValueError(f"model {model!r} does not support d={d}")
         self.N = int(self.lib.dgp_padded_n(self.n))
         handle = C.c_void_p()
-        _lib.check(self.lib.dgp_plan_create(MODELS[model], _DTYPES[dtype], self.n, self.d, C.byref(handle)), "dgp_plan_create")
+        _lib.check(self.lib.dgp_plan_create(mid, _DTYPES[dtype], self.n, self.d, C.byref(handle)), "dgp_plan_create")
         self._h = handle
         self.batch = int(batch)
         if self.batch != 1:

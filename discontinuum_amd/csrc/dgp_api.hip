@@ -149,6 +149,13 @@ extern "C" {
 int dgp_version(void) { return 1; }
 const char* dgp_last_error(void) { return g_err; }
 int dgp_model_ntheta(int model, int d) { return model_ntheta(model, d); }
+int dgp_composite_define(const int* spec, int nspec, int* model_out) {
+  if (!spec || nspec < 2 || !model_out) return fail(DGP_E_ARG, "dgp_composite_define: null argument");
+  const int id = composite_define(spec, nspec);
+  if (id < 0) return fail(DGP_E_MODEL, "dgp_composite_define: malformed or unsupported kernel description");
+  *model_out = id;
+  return 0;
+}
 int64_t dgp_padded_n(int64_t n) { return round_up(n, DGP_TILE_HOST); }
 
 int dgp_plan_create(int model, int dtype, int64_t n, int d, dgp_plan** out) {

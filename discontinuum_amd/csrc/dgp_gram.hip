@@ -9,6 +9,8 @@
 //               streams S = K^^-1 once (N(N+64)/2 * sizeof(T) read), recomputes every sub-kernel in
 //               registers, wave-shuffle + LDS block reduction, deterministic two-stage sum.
 // Coordinates are SoA (d x N) so that the strip loads are coalesced; strips are staged in LDS.
+#include <mutex>
+#include <string.h>
 #include "dgp_internal.h"
 #include "dgp_models.h"
 
@@ -16,9 +18,69 @@ namespace dgp {
 
 size_t pre_scratch_bytes(int B) { return B > DGP_MAX_BATCH ? (size_t)B * DGP_PRE_SLOT_BYTES : 0; }
 
+// ---- registry of generic composite models (dgp_composite_define) -------------------------------------------------
+#define DGP_C_MAXMODELS 64
+static CompositeDesc g_comp[DGP_C_MAXMODELS];
+static int g_ncomp = 0;
+static std::mutex g_comp_mtx;
+static thread_local const CompositeDesc* g_comp_cur = nullptr;
+const CompositeDesc* composite_current() { return g_comp_cur; }
+static const CompositeDesc* composite_get(int model) {
+  const int slot = model - DGP_MODEL_COMPOSITE_BASE;
+  return (slot >= 0 && slot < g_ncomp) ? &g_comp[slot] : nullptr;
+}
+
+// spec: [d, nterms, then per term: scaled (0/1), nfac, then per factor: type, 2 nu, ard (0/1), ndims, dims...].
+// theta order: per term [outputscale if scaled], per factor [lengthscale(s)], [period if periodic].
+// Returns the model id (>= DGP_MODEL_COMPOSITE_BASE; an identical description registered before is reused), or a
+// negative DGP_E_* code.
+int composite_define(const int* spec, int nspec) {
+  CompositeDesc c;
+  memset(&c, 0, sizeof(c));
+  int i = 0, th = 0;
+  auto next = [&](int& v) { if (i >= nspec) return false; v = spec[i++]; return true; };
+  int d, nterms;
+  if (!next(d) || !next(nterms) || d < 1 || d > DGP_C_DMAX || nterms < 1 || nterms > DGP_C_TMAX) return -2;
+  c.d = (unsigned char)d;
+  c.nterms = (unsigned char)nterms;
+  for (int t = 0; t < nterms; ++t) {
+    int scaled, nfac;
+    if (!next(scaled) || !next(nfac) || nfac < 1 || nfac > DGP_C_FMAX) return -2;
+    c.term[t].os = scaled ? (signed char)th++ : (signed char)-1;
+    c.term[t].nfac = (unsigned char)nfac;
+    for (int f = 0; f < nfac; ++f) {
+      int type, nu2, ard, ndims;
+      if (!next(type) || !next(nu2) || !next(ard) || !next(ndims) || ndims < 1 || ndims > d) return -2;
+      if (type != DGP_FAC_RBF && type != DGP_FAC_MATERN && type != DGP_FAC_PERIODIC) return -2;
+      if (type == DGP_FAC_MATERN && nu2 != 1 && nu2 != 3 && nu2 != 5) return -2;
+      if (type == DGP_FAC_PERIODIC && ndims != 1) return -2;  // one column per periodic factor
+      CompositeDesc::Fac& fc = c.term[t].fac[f];
+      fc.type = (unsigned char)type; fc.nu2 = (unsigned char)nu2; fc.ard = ard ? 1 : 0; fc.ndims = (unsigned char)ndims;
+      for (int j = 0; j < ndims; ++j) {
+        int col;
+        if (!next(col) || col < 0 || col >= d) return -2;
+        fc.dims[j] = (unsigned char)col;
+      }
+      fc.ls = (signed char)th;
+      th += ard ? ndims : 1;
+      fc.period = type == DGP_FAC_PERIODIC ? (signed char)th++ : (signed char)-1;
+      if (th > DGP_MAX_THETA) return -2;
+    }
+  }
+  if (i != nspec) return -2;
+  c.ntheta = (unsigned char)th;
+  std::lock_guard<std::mutex> lock(g_comp_mtx);
+  for (int k = 0; k < g_ncomp; ++k)
+    if (memcmp(&g_comp[k], &c, sizeof(c)) == 0) return DGP_MODEL_COMPOSITE_BASE + k;
+  if (g_ncomp >= DGP_C_MAXMODELS) return -2;
+  g_comp[g_ncomp] = c;
+  return DGP_MODEL_COMPOSITE_BASE + g_ncomp++;
+}
+
 int model_ntheta(int model, int d) {
   if (model == DGP_MODEL_LOADEST) return (d >= 2 && d <= 6) ? 2 * d + 5 : -1;
   if (model == DGP_MODEL_RATING) return d == 2 ? 16 : -1;
+  if (const CompositeDesc* c = composite_get(model)) return c->d == d ? c->ntheta : -1;
   return -1;
 }
 
@@ -453,7 +515,18 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ 
       if (d != 2) return -2;                                 \
       { using M = Rating<T>; CALL; }                         \
       break;                                                 \
-    default: return -2;                                      \
+    default:                                                 \
+      g_comp_cur = composite_get(model);                     \
+      if (!g_comp_cur || g_comp_cur->d != d) return -2;      \
+      switch (d) {                                           \
+        case 1: { using M = Composite<T, 1>; CALL; } break;  \
+        case 2: { using M = Composite<T, 2>; CALL; } break;  \
+        case 3: { using M = Composite<T, 3>; CALL; } break;  \
+        case 4: { using M = Composite<T, 4>; CALL; } break;  \
+        case 5: { using M = Composite<T, 5>; CALL; } break;  \
+        case 6: { using M = Composite<T, 6>; CALL; } break;  \
+        default: return -2;                                  \
+      }                                                      \
   }
 
 template <typename T>

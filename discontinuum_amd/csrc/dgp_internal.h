@@ -20,6 +20,7 @@ struct Batch {
   const int* ns = nullptr;  // device array of the sites' own sizes n_b <= n (ragged batch), or null: all n
 };
 int model_ntheta(int model, int d);  // number of constrained kernel hyperparameters, -1 if unsupported
+int composite_define(const int* spec, int nspec);  // register a generic composite model (dgp_models.h), -> model id or < 0
 
 // ---- dgp_gram.hip ---------------------------------------------------------------------------
 template <typename T>

@@ -282,6 +282,141 @@ struct Rating {
   }
 };
 
+// ------------------------------------------------------------------------------------------
+// Composite<T, D>: the GENERIC evaluator -- any sum of (optionally scaled) products of stationary factors
+//     K = sum_t sigma_t^2 prod_f k_tf,   k in { RBF, Matern(nu = 1/2, 3/2, 5/2), Periodic } on a subset of the D columns,
+// one shared or one per-dimension (ARD) lengthscale per factor -- e.g. the reference's unused trend term
+// ScaleKernel(RBF(time)) (src/loadest_gp/models/gpytorch.py:78-88) added to its covariance, or any other model a user
+// composes from the gpytorch-shaped classes of discontinuum_amd.gp.kernels.  The tree is described by a small table
+// (CompositeDesc, registered once through dgp_composite_define) that the pair evaluator INTERPRETS: a slow path next to
+// the two fused models (every derivative goes to a dynamically indexed accumulator, the periodic factor pays a sinpi
+// per pair), but the same kernels, the same C ABI and the same parity tests.
+#define DGP_C_TMAX 6   // terms
+#define DGP_C_FMAX 3   // factors per term
+#define DGP_C_DMAX 6   // active columns per factor
+#define DGP_MODEL_COMPOSITE_BASE 16
+enum { DGP_FAC_RBF = 0, DGP_FAC_MATERN = 1, DGP_FAC_PERIODIC = 2 };
+struct CompositeDesc {
+  unsigned char nterms, ntheta, d, pad;
+  struct Fac {
+    unsigned char type, nu2 /* 2 nu: 1, 3, 5 */, ndims, ard;
+    signed char ls /* index of the (first) lengthscale in theta */, period /* index of the period, or -1 */;
+    unsigned char dims[DGP_C_DMAX];
+  };
+  struct Term {
+    signed char os;  // index of the outputscale in theta, or -1: unscaled
+    unsigned char nfac;
+    Fac fac[DGP_C_FMAX];
+  } term[DGP_C_TMAX];
+};
+const CompositeDesc* composite_current();  // descriptor of the model being dispatched (host, thread-local; dgp_gram.hip)
+
+template <typename T, int D>
+struct Composite {
+  static constexpr int NX = D, NF = D, NTHETA = DGP_MAX_THETA;
+  struct Pre {
+    CompositeDesc desc;
+    T pv[DGP_MAX_THETA];  // outputscale -> sigma^2, lengthscale -> 1 / l, period -> 1 / p
+  };
+  static Pre prepare(const double* th) {
+    Pre p;
+    p.desc = *composite_current();
+    for (int i = 0; i < DGP_MAX_THETA; ++i) p.pv[i] = T(0);
+    for (int t = 0; t < p.desc.nterms; ++t) {
+      const CompositeDesc::Term& tm = p.desc.term[t];
+      if (tm.os >= 0) p.pv[tm.os] = (T)th[tm.os];
+      for (int f = 0; f < tm.nfac; ++f) {
+        const CompositeDesc::Fac& fc = tm.fac[f];
+        for (int j = 0; j < (fc.ard ? fc.ndims : 1); ++j) p.pv[fc.ls + j] = (T)(1.0 / th[fc.ls + j]);
+        if (fc.period >= 0) p.pv[fc.period] = (T)(1.0 / th[fc.period]);
+      }
+    }
+    return p;
+  }
+  static __device__ __forceinline__ void features(const T (&x)[NX], const Pre&, T (&f)[NF]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) f[j] = x[j];
+  }
+  // value of one factor; *aux = the factor's common derivative weight: d v / d l_j = aux * z_j^2 * inv_l_j (stationary
+  // factors, z_j = delta_j / l_j); for the periodic factor aux = v and the caller uses s, c
+  static __device__ __forceinline__ T factor(const CompositeDesc::Fac& fc, const T (&fi)[NF], const T (&fj)[NF], const T* pv,
+                                             T* aux, T* sper, T* cper, T* dper) {
+    if (fc.type == DGP_FAC_PERIODIC) {
+      const T dt = fi[fc.dims[0]] - fj[fc.dims[0]];
+      double sd, cd;
+      sincospi((double)dt * (double)pv[fc.period], &sd, &cd);
+      const T s = (T)sd;
+      const T v = exp_nonpos(T(-2) * s * s * pv[fc.ls]);
+      *aux = v;
+      *sper = s;
+      *cper = (T)cd;
+      *dper = dt;
+      return v;
+    }
+    T sq = T(0);
+    for (int j = 0; j < fc.ndims; ++j) {
+      const T z = (fi[fc.dims[j]] - fj[fc.dims[j]]) * pv[fc.ls + (fc.ard ? j : 0)];
+      sq += z * z;
+    }
+    if (fc.type == DGP_FAC_RBF) {
+      const T v = exp_nonpos(T(-0.5) * sq);
+      *aux = v;
+      return v;
+    }
+    const T r = sqrt_nonneg(sq);
+    if (fc.nu2 == 1) {  // exp(-r);  d/dl_j = exp(-r) z_j^2 / (r l_j)
+      const T e = exp_nonpos(-r);
+      *aux = sq > T(1e-60) ? e / r : T(0);
+      return e;
+    }
+    if (fc.nu2 == 3) {  // (1 + sqrt3 r) exp(-sqrt3 r);  d/dl_j = 3 exp(-sqrt3 r) z_j^2 / l_j
+      const T q = T(1.73205080756887729353) * r;
+      const T e = exp_nonpos(-q);
+      *aux = T(3) * e;
+      return (T(1) + q) * e;
+    }
+    const T q = T(2.23606797749978969641) * r;  // (1 + q + q^2 / 3) exp(-q);  d/dl_j = 5/3 (1 + q) exp(-q) z_j^2 / l_j
+    const T e = exp_nonpos(-q);
+    *aux = T(5.0 / 3.0) * (T(1) + q) * e;
+    return (T(1) + q + q * q * T(1.0 / 3.0)) * e;
+  }
+  template <bool GRAD>
+  static __device__ __forceinline__ T pair(const T (&fi)[NF], const T (&fj)[NF], const Pre& p, T w, T (&acc)[NTHETA]) {
+    T k = T(0);
+    for (int t = 0; t < p.desc.nterms; ++t) {
+      const CompositeDesc::Term& tm = p.desc.term[t];
+      T v[DGP_C_FMAX], aux[DGP_C_FMAX], sp[DGP_C_FMAX], cp[DGP_C_FMAX], dp[DGP_C_FMAX];
+      T prod = T(1);
+      for (int f = 0; f < tm.nfac; ++f) {
+        v[f] = factor(tm.fac[f], fi, fj, p.pv, &aux[f], &sp[f], &cp[f], &dp[f]);
+        prod *= v[f];
+      }
+      const T os = tm.os >= 0 ? p.pv[tm.os] : T(1);
+      k += os * prod;
+      if (GRAD) {
+        if (tm.os >= 0) acc[tm.os] += w * prod;
+        for (int f = 0; f < tm.nfac; ++f) {
+          const CompositeDesc::Fac& fc = tm.fac[f];
+          T others = w * os;
+          for (int g = 0; g < tm.nfac; ++g) others *= (g == f) ? T(1) : v[g];
+          if (fc.type == DGP_FAC_PERIODIC) {
+            const T inv_l = p.pv[fc.ls], inv_p = p.pv[fc.period];
+            acc[fc.ls] += others * aux[f] * T(2) * sp[f] * sp[f] * inv_l * inv_l;
+            acc[fc.period] += others * aux[f] * T(4.0 * 3.14159265358979323846) * dp[f] * sp[f] * cp[f] * inv_l * inv_p * inv_p;
+          } else {
+            for (int j = 0; j < fc.ndims; ++j) {
+              const int q = fc.ls + (fc.ard ? j : 0);
+              const T z = (fi[fc.dims[j]] - fj[fc.dims[j]]) * p.pv[q];
+              acc[q] += others * aux[f] * z * z * p.pv[q];
+            }
+          }
+        }
+      }
+    }
+    return k;
+  }
+};
+
 // Hyperparameters of a batch, blockIdx.z selects the site: up to DGP_MAX_BATCH sites travel by value in the kernel
 // argument segment (SGPR loads, nothing to upload); larger batches read them from a device array (`dev`) that the
 // launcher fills with one small asynchronous copy per fit step.

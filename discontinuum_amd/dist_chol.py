@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .backend import _DTYPES, _ptr, _stream, _theta_array, MODELS
+from .backend import _DTYPES, _ptr, _stream, _theta_array, model_id
 
 
 class DistributedFit:
@@ -38,8 +38,7 @@ class DistributedFit:
 
     def __init__(self, model: str, n: int, d: int, dtype=torch.float64, device="cuda", rank: int | None = None,
                  world: int | None = None, group_panels: int = 4, group=None, lookahead: bool = True):
-        if model not in MODELS:
-            raise ValueError(f"unknown model {model!r}")
+        mid = model_id(model)
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.lib = _lib.load()
@@ -54,10 +53,10 @@ class DistributedFit:
         self.model, self.n, self.d, self.dtype, self.device = model, int(n), int(d), dtype, torch.device(device)
         self.lookahead = bool(lookahead)
         h = C.c_void_p()
-        _lib.check(self.lib.dgp_dist_create(MODELS[model], _DTYPES[dtype], self.n, self.d, self.rank, self.world,
+        _lib.check(self.lib.dgp_dist_create(mid, _DTYPES[dtype], self.n, self.d, self.rank, self.world,
                                             int(group_panels), C.byref(h)), "dgp_dist_create")
         self._h = h
-        self.ntheta = self.lib.dgp_model_ntheta(MODELS[model], self.d)
+        self.ntheta = self.lib.dgp_model_ntheta(mid, self.d)
         self.N = int(self.lib.dgp_dist_padded_n(h))
         self.ngroups = int(self.lib.dgp_dist_groups(h))
         self.W = int(group_panels)

@@ -3,7 +3,11 @@
 The hot path implements exactly the two composite covariance functions the reference ships
 (SURVEY.md section 8a rows a1-a9).  ``lower()`` checks the tree against those shapes and returns the
 model id plus a differentiable builder of the constrained hyperparameter vector in the order the
-device code expects.  Anything else raises ``NotImplementedError`` -- there is no generic slow path.
+device code expects.  A tree that is neither of them but is a sum of (optionally scaled) products of RBF / Matern /
+Periodic factors -- e.g. the reference's covariance with its unused trend term switched on
+(``src/loadest_gp/models/gpytorch.py:78-88``) -- lowers onto the GENERIC interpreted evaluator
+(``dgp_composite_define``, ``csrc/dgp_models.h::Composite``): slower per matrix entry, same kernels and ABI otherwise.
+Anything else (gates, warps, nested sums inside products) raises ``UnsupportedKernelError``.
 """
 from __future__ import annotations
 
@@ -109,10 +113,69 @@ def _lower_rating(cov, d):
     return "rating", theta
 
 
+_FACTOR_TYPES = {K.RBFKernel: 0, K.MaternKernel: 1, K.PeriodicKernel: 2}
+
+
+def composite_spec(covar_module, d):
+    """-> (spec ints for ``dgp_composite_define``, [modules whose constrained values make theta, in order])."""
+    terms = list(covar_module.kernels) if isinstance(covar_module, K.AdditiveKernel) else [covar_module]
+    _need(1 <= len(terms) <= 6, "at most 6 additive terms")
+    spec, parts = [int(d), len(terms)], []
+    for term in terms:
+        scaled = isinstance(term, K.ScaleKernel)
+        base = term.base_kernel if scaled else term
+        factors = list(base.kernels) if isinstance(base, K.ProductKernel) else [base]
+        _need(1 <= len(factors) <= 3, "at most 3 factors per term")
+        spec += [int(scaled), len(factors)]
+        if scaled:
+            parts.append((term, "outputscale"))
+        for fac in factors:
+            _need(type(fac) in _FACTOR_TYPES, "RBF / Matern / Periodic factors")
+            dims = _dims(fac)
+            dims = tuple(range(d)) if dims is None else dims
+            _need(1 <= len(dims) <= 6 and all(0 <= c < d for c in dims), "active_dims inside the design matrix")
+            nls = fac.raw_lengthscale.shape[-1]
+            _need(nls in (1, len(dims)), "one lengthscale, or one per active column")
+            ard = int(nls == len(dims) and len(dims) > 1)
+            kind = _FACTOR_TYPES[type(fac)]
+            if kind == 2:
+                _need(len(dims) == 1 and fac.raw_period_length.numel() == 1, "PeriodicKernel on one column")
+            spec += [kind, int(round(2 * fac.nu)) if kind == 1 else 0, ard, len(dims), *dims]
+            parts.append((fac, "lengthscale"))
+            if kind == 2:
+                parts.append((fac, "period_length"))
+    return spec, parts
+
+
+def _lower_composite(cov, d):
+    import ctypes as C
+
+    from .. import _lib
+
+    spec, parts = composite_spec(cov, d)
+    arr = (C.c_int * len(spec))(*spec)
+    model = C.c_int()
+    try:
+        _lib.check(_lib.load().dgp_composite_define(arr, len(spec), C.byref(model)), "dgp_composite_define")
+    except _lib.DGPError as e:
+        raise UnsupportedKernelError(str(e)) from None
+
+    def theta():
+        return _flat(*[getattr(mod, attr) for mod, attr in parts])
+
+    return f"composite:{model.value}", theta
+
+
 def lower(covar_module, d):
     """-> (model name for ``backend.GPPlan``, zero-argument callable returning theta (P,) float64 with grad)."""
-    _need(isinstance(covar_module, K.AdditiveKernel), "a sum of scaled kernels")
-    first = covar_module.kernels[0]
-    if isinstance(first, K.ProductKernel) and any(isinstance(k, K.SigmoidKernel) for k in first.kernels):
-        return _lower_rating(covar_module, d)
-    return _lower_loadest(covar_module, d)
+    first = covar_module.kernels[0] if isinstance(covar_module, K.AdditiveKernel) else None
+    try:
+        _need(first is not None, "a sum of scaled kernels")
+        if isinstance(first, K.ProductKernel) and any(isinstance(k, K.SigmoidKernel) for k in first.kernels):
+            return _lower_rating(covar_module, d)
+        return _lower_loadest(covar_module, d)
+    except UnsupportedKernelError as fused:
+        try:
+            return _lower_composite(covar_module, d)
+        except UnsupportedKernelError as generic:
+            raise UnsupportedKernelError(f"{fused}; and not a generic composite either: {generic}") from None

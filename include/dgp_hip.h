@@ -16,6 +16,7 @@
  *            (src/loadest_gp/models/gpytorch.py:61-128)
  *        1 = rating-gp composite kernel, d = 2 (time, stage), 16 constrained hyperparameters
  *            (src/rating_gp/models/gpytorch.py:205-372, src/rating_gp/models/kernels.py:242-382)
+ *        >= 16: a generic composite model registered with dgp_composite_define (below)
  *        parameter order: DESIGN.md section "Hyperparameter vectors".
  */
 #ifndef DGP_HIP_H
@@ -64,6 +65,16 @@ int dgp_version(void);
 const char* dgp_last_error(void);
 /* number of constrained kernel hyperparameters of (model, d); <0 if unsupported */
 int dgp_model_ntheta(int model, int d);
+/* A GENERIC model: any sum of (optionally scaled) products of stationary factors -- RBF, Matern(nu = 1/2, 3/2, 5/2),
+ * Periodic -- on subsets of the d <= 6 input columns, e.g. the reference's covariance with its unused trend term
+ * (src/loadest_gp/models/gpytorch.py:78-88) switched on.  `spec` (host ints) describes the tree:
+ *     d, nterms, then per term:  scaled (0/1), nfactors (<= 3), then per factor:
+ *         type (0 RBF, 1 Matern, 2 Periodic), 2 nu (Matern: 1, 3, 5; else 0), ard (0/1), ndims, the ndims column indices
+ * (<= 6 terms, Periodic factors on one column).  The constrained hyperparameters follow the same order: per term
+ * [outputscale if scaled], per factor [lengthscale: one, or one per column if ard], [period if Periodic]; at most 24.
+ * *model_out (>= 16) is then accepted wherever a model id is (dgp_plan_create, dgp_dist_create, dgp_model_ntheta).  An
+ * interpreted evaluator: slower per matrix entry than the two fused models, same kernels otherwise. */
+int dgp_composite_define(const int* spec_host, int nspec, int* model_out);
 /* padded order N = round_up(n, 128) used by every N x N buffer */
 int64_t dgp_padded_n(int64_t n);
 

@@ -194,6 +194,47 @@ def rating_gram(X1, X2, theta):
 GRAMS = {"loadest": loadest_gram, "rating": rating_gram}
 
 
+def composite_gram(spec):
+    """Gram function of a GENERIC composite kernel -- a sum of (optionally scaled) products of RBF / Matern / Periodic
+    factors on subsets of the columns -- from the same integer description the product hands to ``dgp_composite_define``
+    (``discontinuum_amd.gp.lowering.composite_spec``): [d, nterms, per term: scaled, nfactors, per factor: type (0 RBF,
+    1 Matern, 2 Periodic), 2 nu, ard, ndims, columns...].  theta order: per term [outputscale], per factor
+    [lengthscale(s)], [period].  gpytorch semantics as above."""
+    spec = [int(v) for v in spec]
+
+    def gram(X1, X2, theta):
+        i, t = 2, 0
+        total = 0.0
+        for _term in range(spec[1]):
+            scaled, nfac = spec[i], spec[i + 1]
+            i += 2
+            os = 1.0
+            if scaled:
+                os = theta[t]
+                t += 1
+            prod = 1.0
+            for _f in range(nfac):
+                kind, nu2, ard, nd = spec[i:i + 4]
+                dims = spec[i + 4:i + 4 + nd]
+                i += 4 + nd
+                nls = nd if ard else 1
+                ls = theta[t:t + nls]
+                t += nls
+                a, b = X1[:, dims], X2[:, dims]
+                if kind == 0:
+                    val = rbf(a, b, ls)
+                elif kind == 1:
+                    val = matern(a, b, ls, nu2 / 2.0)
+                else:
+                    val = periodic(a, b, ls, theta[t])
+                    t += 1
+                prod = prod * val
+            total = total + os * prod
+        return total
+
+    return gram
+
+
 # --------------------------------------------------------------------------
 # Gaussian marginal likelihood pieces (SURVEY Appendix A.6)
 # --------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""n = 8192: ONE batched plan of 8 sites against TWO batched plans of 4 sites on two streams (fits/s)."""
+"""n = 8192: ONE batched plan of 32 sites against several smaller batched plans on separate streams (fits/s)."""
 import sys, time, os
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -10,7 +10,7 @@ def mk(B, seed0):
     p = GPPlan("loadest", n, d, dtype=dt, device=dev, lookahead=1, batch=B)
     p.set_inputs(torch.tensor(np.stack(Xs), device=dev).contiguous())
     return p, torch.tensor(np.stack(ys), device=dev).contiguous(), torch.full((B, n), 0.01, dtype=dt, device=dev), [0.6931471805599453] * (11 * B)
-for cfg in ((8,), (4, 4), (2, 2, 2, 2), (6, 6)):
+for cfg in ((32,), (16, 16), (8, 8, 8, 8), (24, 24)):
     plans = [mk(B, 10 * i) for i, B in enumerate(cfg)]
     streams = [torch.cuda.Stream(device=dev) for _ in cfg]
     def step():

@@ -218,12 +218,31 @@ def test_rating_fit_and_predict():
     assert all(g is not None for g in grads) and any(float(g.abs().sum()) > 0 for g in grads)
 
 
-def test_lowering_rejects_other_structures():
+def test_lowering_of_other_structures():
+    """Trees other than the two fused models: sums of (scaled) products of RBF / Matern / Periodic factors lower onto
+    the generic composite evaluator (the description and the parameter order are checked against the fused loadest
+    model through the oracle); gates, warps and nested sums are rejected."""
+    from discontinuum_amd.gp.lowering import composite_spec
+    from discontinuum_amd.loadest_gp.models import loadest_covariance
+
     k = K.ScaleKernel(K.RBFKernel(active_dims=[0])) + K.ScaleKernel(K.RBFKernel(active_dims=[1]))
+    name, theta = lower(k, 2)
+    assert name.startswith("composite:") and theta().numel() == 4
+    assert lower(K.ScaleKernel(K.RBFKernel()), 2)[0].startswith("composite:")
+    assert lower(k, 2)[0] == name  # an identical description is registered once
+    # the generic description of the loadest covariance reproduces the fused model's Gram with the same theta order
+    cov = loadest_covariance(3)
+    spec, parts = composite_spec(cov, 3)
+    th = torch.cat([getattr(m, a).reshape(-1) for m, a in parts]).detach() * torch.linspace(0.7, 1.4, 11, dtype=torch.float64)
+    X = torch.randn(30, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    assert (orc.composite_gram(spec)(X, X, th) - orc.loadest_gram(X, X, th)).abs().max() < 1e-14
+    assert lower(cov, 3)[0] == "loadest"  # the fused evaluator still takes what it recognises
     with pytest.raises(UnsupportedKernelError):
-        lower(k, 2)
-    with pytest.raises(UnsupportedKernelError):
-        lower(K.ScaleKernel(K.RBFKernel()), 2)
+        lower(K.LogWarpKernel(K.ScaleKernel(K.RBFKernel(active_dims=[1])), dim=1), 2)
+    with pytest.raises(UnsupportedKernelError):  # a sum inside a product
+        lower(K.ScaleKernel(K.RBFKernel(active_dims=[0]) * (K.RBFKernel(active_dims=[1]) + K.MaternKernel(active_dims=[1]))), 2)
+    with pytest.raises(UnsupportedKernelError):  # more columns than the evaluator carries
+        lower(K.ScaleKernel(K.RBFKernel(active_dims=list(range(7)))), 7)
 
 
 def test_nan_objective_guard():

@@ -1,0 +1,142 @@
+"""The GENERIC composite-kernel path (``dgp_composite_define`` / ``csrc/dgp_models.h::Composite``): kernel trees other
+than the two fused models -- sums of (scaled) products of RBF / Matern / Periodic factors, e.g. the reference's
+loadest covariance with its unused trend term switched on (``src/loadest_gp/models/gpytorch.py:78-88``) -- through the
+same C ABI, against the oracle's generic Gram (``oracle.composite_gram`` on the same description).
+Tolerances as for the fused models: Gram 1e-13 abs, NLL 1e-10 rel, gradients / alpha / dnoise 1e-8, posterior 1e-9 / 1e-8."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _trees():
+    from discontinuum_amd.gp import kernels as K
+    from discontinuum_amd.loadest_gp.models import loadest_covariance
+
+    def with_trend(d):  # the reference's covariance + its cov_trend()
+        return K.ScaleKernel(K.RBFKernel(active_dims=[0])) + loadest_covariance(d)
+
+    def zoo(d):  # every factor type, shared and ARD lengthscales, an unscaled term, a 3-factor product
+        return (K.ScaleKernel(K.MaternKernel(nu=0.5, active_dims=[0, 1], ard_num_dims=2))
+                + K.MaternKernel(nu=1.5, active_dims=list(range(d)))
+                + K.ScaleKernel(K.PeriodicKernel(active_dims=[0]) * K.RBFKernel(active_dims=[1]) * K.MaternKernel(nu=2.5, active_dims=[0]))
+                + K.ScaleKernel(K.RBFKernel(active_dims=list(range(d)), ard_num_dims=d)))
+
+    return {"loadest+trend d=3": (with_trend, 3), "loadest+trend d=2": (with_trend, 2), "zoo d=3": (zoo, 3),
+            "single rbf d=1": (lambda d: K.ScaleKernel(K.RBFKernel(active_dims=[0])), 1)}
+
+
+def _case(name, n, seed=0):
+    from discontinuum_amd.gp.lowering import composite_spec, lower
+
+    build, d = _trees()[name]
+    torch.manual_seed(seed)
+    cov = build(d)
+    for p in cov.parameters():
+        with torch.no_grad():
+            p.add_(0.4 * torch.randn_like(p))
+    model, theta_fn = lower(cov, d)
+    assert model.startswith("composite:")
+    spec, _ = composite_spec(cov, d)
+    gram = orc.composite_gram(spec)
+    orc.GRAMS[model] = gram
+    theta = theta_fn().detach()
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(-4.0, 4.0, n))
+    X = torch.tensor(np.concatenate([t[:, None], rng.standard_normal((n, d - 1))], axis=1))
+    r = torch.tensor(rng.standard_normal(n))
+    noise = torch.full((n,), 0.05, dtype=torch.float64)
+    return model, d, X, r, noise, theta
+
+
+@pytest.mark.parametrize("name,n", [("loadest+trend d=3", 700), ("loadest+trend d=2", 300), ("zoo d=3", 500),
+                                    ("single rbf d=1", 200)])
+def test_generic_model_fit_step_and_predict_fp64(name, n, gpu_device):
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev = gpu_device
+    model, d, X, r, noise, theta = _case(name, n)
+    P = theta.numel()
+    p = GPPlan(model, n, d, device=dev)
+    assert p.ntheta == P
+    p.set_inputs(X.to(dev).contiguous())
+    p.stage_gram(theta, noise.to(dev))
+    Khat = orc.GRAMS[model](X, X, theta) + torch.diag(noise)
+    A = torch.tril(p.buffer(_lib.BUF_A)[:n, :n]).cpu()
+    assert (A - torch.tril(Khat)).abs().max() < 1e-13
+    val, g_theta, g_r, g_noise = orc.nll_data_and_grads(model, X, r, noise, theta)
+    out, dr, dnoise = p.fit_step(theta, r.to(dev), noise.to(dev))
+    out = out.cpu()
+    assert out[_lib.OUT_INFO] == 0
+    assert abs(out[_lib.OUT_NLL] - val) <= 1e-10 * abs(val)
+    g = out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + P]
+    assert (g - g_theta).abs().max() <= 1e-8 * g_theta.abs().max(), (g, g_theta)
+    assert (dr.cpu() - g_r).abs().max() <= 1e-8 * g_r.abs().max()
+    assert (dnoise.cpu() - g_noise).abs().max() <= 1e-8 * g_noise.abs().max()
+    Xs = X[::3] + 0.01
+    mu_ref, var_ref = orc.posterior(model, X, r, noise, theta, Xs)
+    mu, var = p.predict(theta, Xs.to(dev).contiguous())
+    assert (mu.cpu() - mu_ref).abs().max() < 1e-9
+    assert ((var.cpu() - var_ref).abs() / (var_ref.abs() + 1e-12)).max() < 1e-7
+    # the differentiable mean (penalty path) and a batched plan run through the generic evaluator too
+    w = torch.randn(Xs.shape[0], dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    th, rr, nn = (t.clone().requires_grad_(True) for t in (theta, r, noise))
+    m_ref, _ = orc.posterior(model, X, rr, nn, th, Xs)
+    gt, gr_, gn = torch.autograd.grad((m_ref * w).sum(), (th, rr, nn))
+    dtheta, dr2, dn2 = p.mean_vjp(theta, Xs.to(dev).contiguous(), w.to(dev))
+    assert (dtheta.cpu() - gt).abs().max() <= 1e-7 * gt.abs().max()
+    pb = GPPlan(model, n, d, device=dev, lookahead=1, batch=3)
+    pb.set_inputs(X.to(dev).repeat(3, 1, 1).contiguous())
+    ob = pb.fit_step(theta.repeat(3, 1), r.to(dev).repeat(3, 1).contiguous(), noise.to(dev).repeat(3, 1).contiguous())[0].cpu()
+    assert (ob[:, 0] - out[0]).abs().max() <= 1e-11 * abs(out[0])
+
+
+def test_generic_model_through_the_engine_surface(gpu_device):
+    """A user switches the reference's unused trend term on: the model class only overrides the covariance; fit /
+    predict / sample run on the generic evaluator; the objective matches the oracle at the fitted parameters."""
+    from discontinuum_amd import gp
+    from discontinuum_amd.gp import kernels as K
+    from discontinuum_amd.gp.lowering import composite_spec, lower
+    from discontinuum_amd.gp.mll import ExactMarginalLogLikelihood
+    from discontinuum_amd.gp.priors import GammaPrior, HalfNormalPrior
+    from discontinuum_amd.loadest_gp import LoadestGP
+    from discontinuum_amd.loadest_gp.models import ExactGPModel, loadest_covariance
+    from tests.helpers import loadest_dataset
+
+    class TrendModel(ExactGPModel):
+        def __init__(self, train_x, train_y, likelihood):
+            super().__init__(train_x, train_y, likelihood)
+            trend = K.ScaleKernel(K.RBFKernel(active_dims=[0], lengthscale_prior=GammaPrior(concentration=4, rate=1)),
+                                  outputscale_prior=HalfNormalPrior(scale=1))
+            self.covar_module = trend + loadest_covariance(train_x.shape[1])
+
+    class TrendGP(LoadestGP):
+        def build_model(self, X, y):
+            fixed = torch.full((1, y.shape[0]), 0.01, dtype=y.dtype)
+            self.likelihood = gp.likelihoods.FixedNoiseGaussianLikelihood(noise=fixed, learn_additional_noise=False)
+            return TrendModel(X, y, self.likelihood)
+
+    torch.manual_seed(0)
+    cov_ds, tgt = loadest_dataset(250)
+    m = TrendGP()
+    m.fit(cov_ds, tgt, iterations=12)
+    assert m.is_fitted and m._plan.model.startswith("composite:")
+    obj = -ExactMarginalLogLikelihood(m.likelihood, m.model)(m._prior(), m._train_y)
+    spec, _ = composite_spec(m.model.covar_module, 2)
+    theta = lower(m.model.covar_module, 2)[1]().detach()
+    X, y = torch.tensor(m.X), torch.tensor(m.y)
+    c = m.model.mean_module.constant.detach()
+    Khat = orc.composite_gram(spec)(X, X, theta) + 0.01 * torch.eye(X.shape[0], dtype=torch.float64)
+    nll = orc.nll_data(Khat, y - c)
+    from discontinuum_amd.gp.kernels import named_priors
+    lp = sum(prior.log_prob(v).sum() for _n, prior, v in named_priors(m.model))
+    ref = (nll - lp.detach()) / X.shape[0]
+    assert abs(obj.item() - ref.item()) <= 1e-9 * max(1.0, abs(ref.item()))
+    target, se = m.predict(cov_ds)
+    assert np.all(np.isfinite(target.values)) and np.all(se.values >= 1.0)
+    draws = m.sample(cov_ds, n=16)
+    assert draws.values.shape == (16, 250) and np.all(np.isfinite(draws.values))
