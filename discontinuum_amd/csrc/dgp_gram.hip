@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt
       (void)M::template pair<true>(fi, fj, pre, w, acc);
     }
   }
+  M::finalize(acc, pre);  // the pair-independent factors of the derivative sums, once per thread
   const int lane = t & 63, wv = t >> 6;
 #pragma unroll
   for (int p = 0; p < M::NTHETA; ++p) {
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(256) void gram_cross_grad_kernel(const T* __restric
       (void)M::template pair<true>(fi, fj, pre, ai * swj[tx * 4 + b], acc);
     }
   }
+  M::finalize(acc, pre);  // the pair-independent factors of the derivative sums, once per thread
   const int lane = t & 63, wv = t >> 6;
 #pragma unroll
   for (int p = 0; p < M::NTHETA; ++p) {
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(256) void gram_grad_slab_kernel(const T* __restrict
       (void)M::template pair<true>(fi, fj, pre, w, acc);
     }
   }
+  M::finalize(acc, pre);  // the pair-independent factors of the derivative sums, once per thread
   const int lane = t & 63, wv = t >> 6;
 #pragma unroll
   for (int p = 0; p < M::NTHETA; ++p) {
