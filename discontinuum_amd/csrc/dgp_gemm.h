@@ -14,9 +14,12 @@
 
 namespace dgp {
 
-template <typename T, bool KC, int ROWS>
+template <typename T, bool KC, int ROWS, int BK_ = 16>
 struct OperandTile {
-  static constexpr int BK = 16;
+  // depth of a k-tile.  16 everywhere in the product: 32 (half as many barrier episodes per flop) measured +3 % stand-alone
+  // on row-contiguous fp64 operands and on fp32 (scripts/gemm_occ.hip: 68.9 -> 70.9, 133.7 -> 137.6 TFLOP/s), -8 % on
+  // k-contiguous fp64 ones, and nothing in situ (lauum 89.4 -> 90.1 ms per 32 sites)
+  static constexpr int BK = BK_;
   static constexpr int EPT = ROWS * BK / 256;  // elements staged per thread per k-tile (8 or 4)
   static constexpr int STRIDE = KC ? (BK + 1) : (ROWS + 16);
   static constexpr int ELEMS = KC ? ROWS * (BK + 1) : BK * (ROWS + 16);
@@ -67,10 +70,10 @@ struct OperandTile {
   }
 };
 
-template <typename T, bool A_KC, bool B_KC, int BM = 128, int BN = 128>
+template <typename T, bool A_KC, bool B_KC, int BM = 128, int BN = 128, int BK = 16>
 struct TileGemm {
-  using OA = OperandTile<T, A_KC, BM>;
-  using OB = OperandTile<T, B_KC, BN>;
+  using OA = OperandTile<T, A_KC, BM, BK>;
+  using OB = OperandTile<T, B_KC, BN, BK>;
   using acc_t = typename Mfma<T>::acc_t;
   static constexpr int MI = BM / 32;  // 16-row MFMA tiles per wave in M
   static constexpr int NI = BN / 32;
@@ -102,7 +105,7 @@ struct TileGemm {
     A += stepA;
     B += stepB;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < BK / 4; ++ks) {
       T fa[MI], fb[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) fa[mi] = OA::frag(sA, wm + mi * 16, ks, lane);
@@ -124,8 +127,9 @@ struct TileGemm {
     const int wm = (w >> 1) * (BM / 2), wn = (w & 1) * (BN / 2);
     T* sA = smem;
     T* sB = smem + OA::ELEMS;
-    const long stepA = A_KC ? 16 : 16 * lda;
-    const long stepB = B_KC ? 16 : 16 * ldb;
+    ktiles = ktiles * 16 / BK;  // callers count k in tiles of 16; every k-range is a multiple of 128
+    const long stepA = A_KC ? BK : BK * lda;
+    const long stepB = B_KC ? BK : BK * ldb;
     T ra[PF][OA::EPT], rb[PF][OB::EPT];
 #pragma unroll
     for (int p = 0; p < PF; ++p)

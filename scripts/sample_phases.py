@@ -23,9 +23,11 @@ for rep in range(2):
     t = time.perf_counter()
     Xnew = torch.tensor(model.dm.Xnew(daily), dtype=model.dtype).to(model.device).contiguous(); t = tick("Xnew (host transform+upload)", t)
     model._ensure_factor(); t = tick("ensure_factor", t)
-    mean, L = model._plan.posterior_factor(model._factor_theta, Xnew); t = tick("posterior_factor", t)
-    z = torch.randn(L.shape[0], 1000, dtype=model.dtype, device=L.device); t = tick("randn", t)
-    sim = (mean[:, None] + L @ z).T.contiguous(); t = tick("L @ z, transpose", t)
+    mean, cov = model._plan.posterior_cov(model._factor_theta, Xnew); t = tick("posterior_cov (n^2 m + m^2 n)", t)
+    Lbuf, jitter = model._plan.psd_safe_factor(cov, Xnew.shape[0]); t = tick(f"psd_safe_factor (jitter {jitter:g})", t)
+    sim = model._plan.sample_draws(Lbuf, Xnew.shape[0], mean, 1000); t = tick("sample_draws (randn + MFMA)", t)
     host = sim.reshape(-1).cpu().numpy(); t = tick("to host", t)
     temp = model.dm.y_t(host); t = tick("y_t (numpy)", t)
+    t0 = time.perf_counter(); model.sample(daily, n=1000); torch.cuda.synchronize()
+    print(f"  sample(n=1000) end to end     {(time.perf_counter() - t0) * 1e3:8.2f} ms")
     print()
