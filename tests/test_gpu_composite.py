@@ -140,3 +140,55 @@ def test_generic_model_through_the_engine_surface(gpu_device):
     assert np.all(np.isfinite(target.values)) and np.all(se.values >= 1.0)
     draws = m.sample(cov_ds, n=16)
     assert draws.values.shape == (16, 250) and np.all(np.isfinite(draws.values))
+
+
+def test_generic_model_on_the_distributed_and_multisite_paths(gpu_device):
+    """The generic evaluator behind the other entry points that take a model id: the column-slab distributed fit (one
+    rank) against the single-GPU fit step, and ``fit_many`` / ``predict_many`` for model classes with the trend term."""
+    from discontinuum_amd import _lib, gp
+    from discontinuum_amd.backend import GPPlan
+    from discontinuum_amd.dist_chol import DistributedFit
+    from discontinuum_amd.gp import kernels as K
+    from discontinuum_amd.loadest_gp import LoadestGP
+    from discontinuum_amd.loadest_gp.models import ExactGPModel, loadest_covariance
+    from discontinuum_amd.multisite_fit import fit_many, predict_many
+    from tests.helpers import loadest_dataset
+
+    dev = gpu_device
+    model, d, X, r, noise, theta = _case("loadest+trend d=3", 900)
+    P = theta.numel()
+    ctx = DistributedFit(model, 900, d, device=dev, group_panels=2)
+    ctx.set_inputs(X.to(dev).contiguous())
+    out = ctx.fit_step(theta, r.to(dev), noise.to(dev)).cpu()
+    p = GPPlan(model, 900, d, device=dev)
+    p.set_inputs(X.to(dev).contiguous())
+    ref = p.fit_step(theta, r.to(dev), noise.to(dev))[0].cpu()
+    assert out[_lib.OUT_INFO] == 0 and abs(out[0] - ref[0]) <= 1e-11 * abs(ref[0])
+    assert (out[4:4 + P] - ref[4:4 + P]).abs().max() <= 1e-9 * ref[4:4 + P].abs().max()
+
+    class TrendModel(ExactGPModel):
+        def __init__(self, train_x, train_y, likelihood):
+            super().__init__(train_x, train_y, likelihood)
+            self.covar_module = K.ScaleKernel(K.RBFKernel(active_dims=[0])) + loadest_covariance(train_x.shape[1])
+
+    class TrendGP(LoadestGP):
+        def build_model(self, X, y):
+            fixed = torch.full((1, y.shape[0]), 0.01, dtype=y.dtype)
+            self.likelihood = gp.likelihoods.FixedNoiseGaussianLikelihood(noise=fixed, learn_additional_noise=False)
+            return TrendModel(X, y, self.likelihood)
+
+    data = [loadest_dataset(k, seed=40 + i) for i, k in enumerate([80, 120])]
+    solo = []
+    for cov_ds, tgt in data:
+        m = TrendGP()
+        m.fit(cov_ds, tgt, iterations=15)
+        solo.append(m)
+    many = [TrendGP() for _ in data]
+    fit_many(many, data, iterations=15)
+    preds = predict_many(many, [c for c, _t in data])
+    for a, b, (cov_ds, _t), (tb, sb) in zip(solo, many, data, preds):
+        pa = torch.cat([q.detach().reshape(-1) for q in a.model.parameters()])
+        pb = torch.cat([q.detach().reshape(-1) for q in b.model.parameters()])
+        assert (pa - pb).abs().max() < 1e-6
+        ta, sa = a.predict(cov_ds)
+        assert np.allclose(ta.values, tb.values, rtol=1e-6) and np.allclose(sa.values, sb.values, rtol=1e-6)
