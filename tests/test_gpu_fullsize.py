@@ -4,6 +4,9 @@ with random probe vectors, and the gradient against central finite differences o
 
 Tolerances: ||L L^T v - K v|| / ||K v|| < 1e-12; ||T L v - v|| / ||v|| < 1e-9; ||S K v - v|| / ||v|| < 1e-8;
 alpha: ||K alpha - r|| / ||r|| < 1e-9; directional derivative vs finite difference rel 1e-6."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +14,14 @@ import torch
 from oracle import gp_oracle as orc
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(**row):
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "fullsize_parity.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
 
 
 def _sym_matvec(M, v):
@@ -69,8 +80,10 @@ def test_full_size_factor_identities_and_gradient(gpu_device):
 
 def test_config3_rating_fp32_full_size(gpu_device):
     """BASELINE config 3: rating-gp kernel, n = 16384, d = 2, fp32 on one GPU.  Size-independent checks in the
-    precision the path computes in: the factor reproduces K^ on probe vectors (rel 2e-5), alpha solves K^ alpha = r
-    (residual rel 5e-2: fp32 against cond(K^) ~ 1e6), the NLL pieces agree with the factor (rel 1e-4)."""
+    precision the path computes in, tolerances = 4x what was measured (gpurun_out/fullsize_parity.jsonl): the factor
+    reproduces K^ on probe vectors (measured 1.5e-6 -> 6e-6), alpha solves K^ alpha = r (residual measured 7.6e-4 -> 3e-3;
+    the dense fp64 comparison at n = 4096, where cond(K^) = 3.2e5 is measured, is tests/test_gpu_fp32.py), the NLL
+    pieces agree with the factor (measured 5e-7 -> 2e-6)."""
     from discontinuum_amd import _lib
     from discontinuum_amd.backend import GPPlan
 
@@ -94,12 +107,16 @@ def test_config3_rating_fp32_full_size(gpu_device):
     out = out.cpu().double()
     assert out[_lib.OUT_INFO] == 0 and torch.isfinite(out[:4 + 16]).all()
     L = torch.tril(p.buffer(_lib.BUF_A))
-    assert (torch.linalg.norm(L @ (L.T @ V) - KV) / torch.linalg.norm(KV)).item() < 2e-5
-    assert (torch.linalg.norm(_sym_matvec(K, alpha[:, None]) - r[:, None]) / torch.linalg.norm(r)).item() < 5e-2
+    e_fac = (torch.linalg.norm(L @ (L.T @ V) - KV) / torch.linalg.norm(KV)).item()
+    e_res = (torch.linalg.norm(_sym_matvec(K, alpha[:, None]) - r[:, None]) / torch.linalg.norm(r)).item()
     logdet = 2.0 * torch.log(torch.diagonal(L).double()).sum().item()
     quad = float((r.double() * alpha.double()).sum())
     nll = 0.5 * quad + 0.5 * logdet + 0.5 * n * np.log(2 * np.pi)
-    assert abs(out[_lib.OUT_NLL].item() - nll) / abs(nll) < 1e-4
+    e_nll = abs(out[_lib.OUT_NLL].item() - nll) / abs(nll)
+    _record(test="config3_rating_n16384_fp32", factor_rel=e_fac, residual_rel=e_res, nll_vs_factor_rel=e_nll)
+    assert e_fac < 6e-6, e_fac
+    assert e_res < 3e-3, e_res
+    assert e_nll < 2e-6, e_nll
 
 
 def test_config4_batch_of_sites_full_size(gpu_device):
@@ -134,7 +151,7 @@ def test_config4_batch_of_sites_full_size(gpu_device):
 
 def test_config5_single_matrix_on_one_gpu(gpu_device):
     """BASELINE config 5's matrix (n = 65536, d = 3, fp32; 48 GiB of workspace) factored on ONE GPU: the system is
-    solved to fp32 accuracy (||K^ alpha - r|| / ||r|| < 2e-2 at cond(K^) ~ 1e6 n; measured 3.6e-3)."""
+    solved to fp32 accuracy (||K^ alpha - r|| / ||r|| measured 3.8e-3; tolerance 1.2e-2)."""
     from discontinuum_amd import _lib
     from discontinuum_amd.backend import GPPlan
 
@@ -162,4 +179,6 @@ def test_config5_single_matrix_on_one_gpu(gpu_device):
         res[lo:hi] = rows @ alpha[:hi] + torch.tril(K[lo:hi, lo:hi], -1).T @ alpha[lo:hi]
         if hi < n:
             res[lo:hi] += K[hi:, lo:hi].T @ alpha[hi:]
-    assert (torch.linalg.norm(res - yd) / torch.linalg.norm(yd)).item() < 2e-2
+    e_res = (torch.linalg.norm(res - yd) / torch.linalg.norm(yd)).item()
+    _record(test="config5_loadest_n65536_fp32", residual_rel=e_res)
+    assert e_res < 1.2e-2, e_res
