@@ -429,3 +429,50 @@ def test_fit_many_clip_matches_the_single_site_loop_on_a_broken_gradient():
             got = grads[k][site] * coef[site]
             assert torch.equal(got, p.grad) or (got - p.grad).abs().max() < 1e-15, (site, k, got, p.grad)
     assert float(coef[1]) == 0.0 and float(coef[3]) == 0.0 and float(coef[2]) == 1.0 and 0 < float(coef[0]) < 1
+
+
+def test_parameter_names_follow_the_reference_module_trees():
+    """The parameter keys of ``state_dict()`` are those gpytorch gives the reference's module trees: attribute names from
+    the reference's model definitions (``mean_module``, ``covar_module``, ``powerlaw.a/b/c``:
+    src/loadest_gp/models/gpytorch.py:61-128, src/rating_gp/models/gpytorch.py:28-40, 205-256), gpytorch's ``raw_*`` names for
+    constrained parameters, ``kernels.<i>`` for the flattened sums / products in the order the reference composes them,
+    ``base_kernel`` under ScaleKernel / LogWarpKernel.  (Buffers of priors and constraints are NOT pinned: whether gpytorch
+    registers them differs between versions -- ``load`` tolerates them)"""
+    cov, tgt = loadest_dataset(20)
+    m = LoadestGP()
+    m.fit(cov, tgt, iterations=1)
+    assert [k for k, _ in m.model.named_parameters()] == [
+        "mean_module.raw_constant",
+        "covar_module.kernels.0.raw_outputscale",                          # cov_seasonal: Scale(Periodic * Matern52)
+        "covar_module.kernels.0.base_kernel.kernels.0.raw_lengthscale",
+        "covar_module.kernels.0.base_kernel.kernels.0.raw_period_length",
+        "covar_module.kernels.0.base_kernel.kernels.1.raw_lengthscale",
+        "covar_module.kernels.1.raw_outputscale",                          # cov_covariates: Scale(RBF)
+        "covar_module.kernels.1.base_kernel.raw_lengthscale",
+        "covar_module.kernels.2.raw_outputscale",                          # cov_residual: Scale(Matern32)
+        "covar_module.kernels.2.base_kernel.raw_lengthscale",
+    ]
+    assert list(m.likelihood.state_dict()) == [] or all("noise" in k for k in m.likelihood.state_dict())
+    cov, tgt, unc = rating_dataset(20)
+    r = RatingGP()
+    r.fit(cov, tgt, target_unc=unc, iterations=1)
+    names = [k for k, _ in r.model.named_parameters()]
+    lower = "covar_module.kernels.0.kernels.1.base_kernel"   # sigmoid_lower * LogWarp(cov_shift + cov_shift)
+    upper = "covar_module.kernels.1.kernels.1.base_kernel"   # sigmoid_upper * LogWarp(cov_bend)
+    rest = "covar_module.kernels.2.base_kernel"              # LogWarp(cov_base + cov_periodic)
+    assert names == [
+        "likelihood.second_noise_covar.raw_noise", "powerlaw.a", "powerlaw.b", "powerlaw.c",
+        "covar_module.kernels.0.kernels.0.raw_b",
+        f"{lower}.kernels.0.raw_outputscale", f"{lower}.kernels.0.base_kernel.kernels.0.raw_lengthscale",
+        f"{lower}.kernels.0.base_kernel.kernels.1.raw_lengthscale",
+        f"{lower}.kernels.1.raw_outputscale", f"{lower}.kernels.1.base_kernel.kernels.0.raw_lengthscale",
+        f"{lower}.kernels.1.base_kernel.kernels.1.raw_lengthscale",
+        f"{upper}.raw_outputscale", f"{upper}.base_kernel.kernels.0.raw_lengthscale", f"{upper}.base_kernel.kernels.1.raw_lengthscale",
+        f"{rest}.kernels.0.raw_outputscale", f"{rest}.kernels.0.base_kernel.raw_lengthscale",
+        f"{rest}.kernels.1.raw_outputscale", f"{rest}.kernels.1.base_kernel.kernels.0.raw_lengthscale",
+        f"{rest}.kernels.1.base_kernel.kernels.0.raw_period_length", f"{rest}.kernels.1.base_kernel.kernels.1.raw_lengthscale",
+    ]
+    # the inverted gate shares the switch point: its state_dict entry is the same tensor under a second name
+    sd = r.model.state_dict()
+    assert "covar_module.kernels.1.kernels.0.sigmoid_kernel.raw_b" in sd
+    assert [k for k, _ in r.likelihood.named_parameters()] == ["second_noise_covar.raw_noise"]
