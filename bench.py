@@ -211,7 +211,7 @@ def time_config(name, model, n, d, dtype_name, S, steps, warmup, dev, lib, level
     ok = bool((host[:, lib.OUT_INFO] == 0).all()) and bool(torch.isfinite(host[:, lib.OUT_NLL]).all())
     rep = stage_report(plan, S, dtype_name, level, lib)
     N = plan.N
-    res = {"workload": name, "model": model, "n": n, "d": d, "dtype": dtype_name, "sites_in_plan": S, "steps": steps,
+    res = {"workload": name, "kernel": f"{model}-gp", "n": n, "d": d, "dtype": dtype_name, "sites_in_plan": S, "steps": steps,
            "ms_per_step": dtm * 1e3, "fits_per_s": S / dtm, "tflops": S * float(N) ** 3 / dtm / 1e12,
            "frac_of_peak": S * float(N) ** 3 / dtm / 1e12 / PEAK_TFLOPS[dtype_name], "ok": ok,
            "nll_site0": float(host[0, lib.OUT_NLL]), "hbm_gib": plan._ws.numel() / 2 ** 30, "lookahead": level,
