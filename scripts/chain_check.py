@@ -1,4 +1,4 @@
-"""Persistent panel-chain kernel (DGP_CHAIN=1) against the launch-per-step chain: bitwise comparison of L, L^-1 and the
+"""Resident diagonal-block server (DGP_DIAG_SERVER=1; earlier: the persistent chain kernel of scripts/persistent_chain.patch) against the launch-per-step chain: bitwise comparison of L, L^-1 and the
 result row, then timings.  usage: python scripts/chain_check.py [dtype] [n ...]"""
 import os, sys, time
 import numpy as np, torch
@@ -17,7 +17,7 @@ for n in ns:
     Xd = torch.tensor(X, dtype=dt, device=dev).contiguous(); rd = torch.tensor(r, dtype=dt, device=dev); nd = torch.tensor(noise, dtype=dt, device=dev)
     res = {}
     for mode in ("0", "1"):
-        os.environ["DGP_CHAIN"] = mode
+        os.environ["DGP_DIAG_SERVER"] = mode
         p = GPPlan("loadest", n, 3, dtype=dt, device=dev, lookahead=level)
         p.set_inputs(Xd)
         out, a, dn = p.fit_step(theta, rd, nd)
