@@ -21,7 +21,8 @@ executed here, so the formulas below follow gpytorch's published semantics
 
 Independent cross-checks that DO run here (tests/test_oracle.py): autograd
 ``gradcheck``; the analytic trace gradient 1/2 tr((K^-1 - aa^T) dK); scipy
-``cho_factor``/``cho_solve``; scikit-learn's RBF / Matern / ExpSineSquared kernels.
+``cho_factor``/``cho_solve``; scikit-learn's RBF / Matern / ExpSineSquared kernels; and end to end scikit-learn's
+GaussianProcessRegressor on both composite covariances (log-marginal likelihood and posterior).
 """
 from __future__ import annotations
 

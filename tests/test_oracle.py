@@ -121,3 +121,126 @@ def test_rating_posterior_noise_semantics():
     theta = m.constrained(raw)
     _, v_lat = orc.posterior("rating", X, y - m.mean(raw, X), m.noise(raw, 30, yu), theta, X[:10])
     assert torch.allclose(v1, v_lat + m.second_noise(raw))
+
+
+def test_loadest_nll_and_posterior_match_scikit_learn_gpr():
+    """END-TO-END anchor on an independent GP implementation: scikit-learn's GaussianProcessRegressor with the loadest-gp
+    covariance composed from scikit-learn's own kernels (ConstantKernel * ExpSineSquared * Matern52 on time + Constant *
+    ARD-RBF on the covariates + Constant * ARD-Matern32 on all columns; the only glue is a column selector).  Its
+    log-marginal likelihood is -NLL_data of the oracle and its latent predictive mean / standard deviation are the
+    oracle's posterior -- kernel composition, A.6's likelihood and the prediction formulas all at once (gpytorch itself
+    cannot run here: the gpytorch boundary stays parity unpinned)."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+
+    class Cols(sk.Kernel):
+        """``kernel`` on the columns ``cols`` of the inputs (scikit-learn kernels have no active_dims)."""
+
+        def __init__(self, kernel, cols):
+            self.kernel, self.cols = kernel, cols
+
+        def __call__(self, X, Y=None, eval_gradient=False):
+            assert not eval_gradient
+            return self.kernel(X[:, self.cols], None if Y is None else Y[:, self.cols])
+
+        def diag(self, X):
+            return self.kernel.diag(X[:, self.cols])
+
+        def is_stationary(self):
+            return True
+
+    d, n, m = 3, 60, 25
+    X, y = orc.synth_loadest(n, d, 11)
+    Xs, _ = orc.synth_loadest(m, d, 12)
+    theta = orc.positive(0.5 * torch.randn(orc.loadest_ntheta(d), dtype=orc.DT, generator=torch.Generator().manual_seed(4)))
+    th = theta.numpy()
+    os1, lp, per, lm, os2, l2a, l2b, os3, l3a, l3b, l3c = th
+    fixed = "fixed"
+    kernel = (sk.ConstantKernel(os1, fixed) * Cols(sk.ExpSineSquared(math.sqrt(lp), per, fixed, fixed), [0])
+              * Cols(sk.Matern(lm, fixed, nu=2.5), [0])
+              + sk.ConstantKernel(os2, fixed) * Cols(sk.RBF([l2a, l2b], fixed), [1, 2])
+              + sk.ConstantKernel(os3, fixed) * sk.Matern([l3a, l3b, l3c], fixed, nu=1.5))
+    noise = np.full(n, 0.01)
+    gpr = GaussianProcessRegressor(kernel=kernel, alpha=noise, optimizer=None, normalize_y=False).fit(X, y)
+    Xt, yt = torch.tensor(X), torch.tensor(y)
+    Khat = orc.loadest_gram(Xt, Xt, theta) + torch.diag(torch.tensor(noise))
+    assert np.allclose(Khat.numpy(), kernel(X) + np.diag(noise), atol=1e-13)
+    nll = orc.nll_data(Khat, yt).item()
+    assert abs(-gpr.log_marginal_likelihood_value_ - nll) < 1e-10 * abs(nll)
+    mu, var = orc.posterior("loadest", Xt, yt, torch.tensor(noise), theta, torch.tensor(Xs))
+    mean_sk, std_sk = gpr.predict(Xs, return_std=True)
+    assert np.allclose(mu.numpy(), mean_sk, atol=1e-10)
+    assert np.allclose(var.numpy(), std_sk ** 2, atol=1e-10)
+
+
+def test_rating_nll_and_posterior_match_scikit_learn_gpr():
+    """The rating-gp covariance on scikit-learn's GaussianProcessRegressor: the Matern / periodic factors, their products and
+    sums are scikit-learn's; the glue restates only the reference's own custom pieces -- the rank-one sigmoid gates with
+    a = 20 and a shared switch point (src/rating_gp/models/kernels.py:242-360) and the log-warp of the stage column
+    (:363-382).  Parameter order: DESIGN.md section 2."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+
+    class Wrap(sk.Kernel):
+        def is_stationary(self):
+            return False
+
+        def diag(self, X):
+            return np.diag(self(X))
+
+    class Cols(Wrap):
+        def __init__(self, kernel, cols):
+            self.kernel, self.cols = kernel, cols
+
+        def __call__(self, X, Y=None, eval_gradient=False):
+            return self.kernel(X[:, self.cols], None if Y is None else Y[:, self.cols])
+
+    class LogWarp(Wrap):
+        def __init__(self, kernel):
+            self.kernel = kernel
+
+        def __call__(self, X, Y=None, eval_gradient=False):
+            def warp(Z):
+                Z = Z.copy()
+                Z[:, 1] = np.log(Z[:, 1] + 1e-6)
+                return Z
+            return self.kernel(warp(X), None if Y is None else warp(Y))
+
+    class Gate(Wrap):
+        def __init__(self, b, inverted):
+            self.b, self.inverted = b, inverted
+
+        def __call__(self, X, Y=None, eval_gradient=False):
+            def g(Z):
+                v = 1.0 / (1.0 + np.exp(20.0 * (Z[:, 1] - self.b)))
+                return 1.0 - v if self.inverted else v
+            return np.outer(g(X), g(X if Y is None else Y))
+
+    n, m = 70, 30
+    X, y, yu = orc.synth_rating(n, 21)
+    Xs, _, _ = orc.synth_rating(m, 22)
+    theta = orc.positive(0.4 * torch.randn(16, dtype=orc.DT, generator=torch.Generator().manual_seed(6)))
+    theta[0] = float(np.median(X[:, 1]))
+    t = theta.numpy()
+    f = "fixed"
+
+    def m52(ls, col):
+        return Cols(sk.Matern(ls, f, nu=2.5), [col])
+
+    def shift(os, ls_s, ls_t):
+        return sk.ConstantKernel(os, f) * m52(ls_s, 1) * Cols(sk.Matern(ls_t, f, nu=1.5), [0])
+
+    lower = shift(*t[1:4]) + shift(*t[4:7])
+    bend = sk.ConstantKernel(t[7], f) * m52(t[8], 1) * m52(t[9], 0)
+    rest = (sk.ConstantKernel(t[10], f) * m52(t[11], 1)
+            + sk.ConstantKernel(t[12], f) * Cols(sk.ExpSineSquared(math.sqrt(t[13]), t[14], f, f), [0]) * m52(t[15], 0))
+    kernel = Gate(t[0], False) * LogWarp(lower) + Gate(t[0], True) * LogWarp(bend) + LogWarp(rest)
+    noise = yu + 0.02
+    Xt, yt = torch.tensor(X), torch.tensor(y)
+    Khat = orc.rating_gram(Xt, Xt, theta) + torch.diag(torch.tensor(noise))
+    assert np.allclose(Khat.numpy(), kernel(X) + np.diag(noise), atol=1e-13)
+    gpr = GaussianProcessRegressor(kernel=kernel, alpha=noise, optimizer=None, normalize_y=False).fit(X, y)
+    nll = orc.nll_data(Khat, yt).item()
+    assert abs(-gpr.log_marginal_likelihood_value_ - nll) < 1e-10 * max(1.0, abs(nll))
+    mu, var = orc.posterior("rating", Xt, yt, torch.tensor(noise), theta, torch.tensor(Xs))
+    mean_sk, std_sk = gpr.predict(Xs, return_std=True)
+    assert np.allclose(mu.numpy(), mean_sk, atol=1e-9)
+    assert np.allclose(var.numpy(), std_sk ** 2, atol=1e-9)
