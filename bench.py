@@ -297,7 +297,7 @@ def main():
                          "n = 8192 fp64; 8 -> 104.5, 16 -> 106.7, 32 -> 107.6 fits/s)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 5],
                     help="2: the headline loop (default); 5: ONE n x n matrix factored and differentiated across all "
-                         "ranks (dist_chol.distributed_fit_step; --size 65536 --dtype f32 is BASELINE config 5)")
+                         "ranks (dist_chol.DistributedFit.fit_step; --size 65536 --dtype f32 is BASELINE config 5)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the per-kernel timing loop of the roofline object (the command profiled with "
                          "rocprofv3 --kernel-trace --stats for profiles/)")
@@ -311,18 +311,29 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     dist = None
-    if world > 1:
+    # DGP_DIST_FORCE_COLLECTIVES=1: a ONE-rank run still creates its communicator and issues every collective (a
+    # world-1 RCCL communicator is legal) -- the only way the RCCL entry points can execute on a one-GPU box
+    force = os.environ.get("DGP_DIST_FORCE_COLLECTIVES", "0") not in ("", "0")
+    if world > 1 or force:
         import torch.distributed as dist  # noqa: PLW0621
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
     # one rank per GPU; DGP_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path on a
     # single-GPU box (RCCL refuses two ranks on one device)
     backend = os.environ.get("DGP_BENCH_BACKEND", "nccl")
     ndev = max(1, torch.cuda.device_count())
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if dist is not None:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -471,7 +482,10 @@ def main():
 
 def run_config5(args, model, d, dev, world, rank, dist, barrier, lib):
     """BASELINE config 5: ONE matrix over all ranks -- distributed factorisation, inverse and gradient
-    (discontinuum_amd/dist_chol.py::distributed_fit_step).  One step = one NLL + gradient evaluation."""
+    (discontinuum_amd/dist_chol.py::DistributedFit.fit_step).  One step = one NLL + gradient evaluation.  The
+    `roofline` object is rank 0's dominant MFMA stage (trailing update / inverse / K^^-1 products): flops counted tile by
+    tile (DistributedFit.stage_flops), time = HIP events around that stage's launches on the stream they run on, in one
+    extra step after the timed region (the events serialise nothing, but they are kept out of `value`)."""
     from discontinuum_amd import dist_chol
 
     dt = torch.float64 if args.dtype == "f64" else torch.float32
@@ -492,18 +506,36 @@ def run_config5(args, model, d, dev, world, rank, dist, barrier, lib):
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    ctx.set_timing(True)
+    for k in ctx.comm.calls:
+        ctx.comm.calls[k] = 0  # `collectives_issued` = what ONE fit step issues
+    ctx.fit_step(theta, rd, nd)  # every rank takes part; rank 0 reports its own stages
+    stage_ms = ctx.get_timing()
     if rank == 0:
         N = ctx.N
         host = out.cpu().double()
+        flops = ctx.stage_flops()
+        dom = max(flops, key=lambda k: stage_ms[k])
+        peak = PEAK_TFLOPS[args.dtype]
+        ach = flops[dom] / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else None
+        names = {"update": "slab_syrk_kernel", "invert": "slab_tconv_kernel + slab_xacc_kernel", "product": "slab_ttt_kernel"}
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                    "frac": ach / peak if ach else None, "traffic": None,
+                    "ms_per_step": stage_ms[dom], "flops_per_step_rank0": flops[dom],
+                    "stages_ms": stage_ms,
+                    "stages_tflops": {k: (flops[k] / (stage_ms[k] * 1e-3) / 1e12 if stage_ms[k] > 0 else None) for k in flops},
+                    "measured_in": "one extra fit step after the timed region, rank 0's launches",
+                    "collectives_issued": dict(ctx.comm.calls)}
         print(json.dumps({
             "metric": METRIC, "value": args.steps / elapsed, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"ONE {model}-gp matrix n={n} d={d} {args.dtype}: block-cyclic distributed Cholesky, "
                                    f"inverse and gradient over {world} rank(s)", "n": n, "d": d,
-                       "nll": float(host[lib.OUT_NLL]), "info": int(host[lib.OUT_INFO])},
+                       "nll": float(host[lib.OUT_NLL]), "info": int(host[lib.OUT_INFO]),
+                       "backend": (dist.get_backend() if dist is not None else None)},
             "job_tflops": float(N) ** 3 * args.steps / elapsed / 1e12,
-            "per_rank_hbm_gib": ctx.hbm_bytes() / 2 ** 30, "cpu_baseline": None, "roofline": None}))
+            "per_rank_hbm_gib": ctx.hbm_bytes() / 2 ** 30, "cpu_baseline": None, "roofline": roofline}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

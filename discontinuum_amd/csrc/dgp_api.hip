@@ -152,6 +152,7 @@ int dgp_model_ntheta(int model, int d) { return model_ntheta(model, d); }
 int dgp_composite_define(const int* spec, int nspec, int* model_out) {
   if (!spec || nspec < 2 || !model_out) return fail(DGP_E_ARG, "dgp_composite_define: null argument");
   const int id = composite_define(spec, nspec);
+  if (id == -5) return fail(DGP_E_MODEL, "dgp_composite_define: the registry is full (64 distinct kernel structures per process)");
   if (id < 0) return fail(DGP_E_MODEL, "dgp_composite_define: malformed or unsupported kernel description");
   *model_out = id;
   return 0;

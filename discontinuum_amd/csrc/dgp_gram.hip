@@ -32,8 +32,8 @@ static const CompositeDesc* composite_get(int model) {
 
 // spec: [d, nterms, then per term: scaled (0/1), nfac, then per factor: type, 2 nu, ard (0/1), ndims, dims...].
 // theta order: per term [outputscale if scaled], per factor [lengthscale(s)], [period if periodic].
-// Returns the model id (>= DGP_MODEL_COMPOSITE_BASE; an identical description registered before is reused), or a
-// negative DGP_E_* code.
+// Returns the model id (>= DGP_MODEL_COMPOSITE_BASE; an identical description registered before is reused), -2 for a
+// malformed / unsupported description, -5 when all DGP_C_MAXMODELS slots hold other structures.
 int composite_define(const int* spec, int nspec) {
   CompositeDesc c;
   memset(&c, 0, sizeof(c));
@@ -72,7 +72,7 @@ int composite_define(const int* spec, int nspec) {
   std::lock_guard<std::mutex> lock(g_comp_mtx);
   for (int k = 0; k < g_ncomp; ++k)
     if (memcmp(&g_comp[k], &c, sizeof(c)) == 0) return DGP_MODEL_COMPOSITE_BASE + k;
-  if (g_ncomp >= DGP_C_MAXMODELS) return -2;
+  if (g_ncomp >= DGP_C_MAXMODELS) return -5;  // registry full (reported as such by dgp_composite_define)
   g_comp[g_ncomp] = c;
   return DGP_MODEL_COMPOSITE_BASE + g_ncomp++;
 }

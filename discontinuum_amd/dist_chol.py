@@ -19,11 +19,19 @@ communication schedule on top of ``torch.distributed`` (backend "nccl" = RCCL ov
   of the n-vector 1/2 (diag K^^-1 - alpha^2)).
 
 Per rank: N^3 / world flops on MFMA and N^2 elements received over both passes (17 GB at n = 65536 fp32).
+
+STATUS of the communication layer: the schedule has run over gloo (ranks as processes sharing one GPU, world 2..5) and
+over ``ThreadComm`` (ranks as threads of one process, world up to 8 and beyond -- the GPU boxes of this project allow at
+most six processes on a card).  The "nccl" (= RCCL) backend has only ever been entered with ONE rank
+(``DGP_DIST_FORCE_COLLECTIVES=1``: a world-1 communicator really calls RCCL's broadcast / all_reduce / all_gather); a run
+on several GPUs has not happened -- its timing is UNMEASURED and its stream-ordering assumptions (below) are UNPINNED.
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
+import os
+import threading
 
 import torch
 import torch.distributed as dist
@@ -32,24 +40,156 @@ from . import _lib
 from .backend import _DTYPES, _ptr, _stream, _theta_array, model_id
 
 
-class DistributedFit:
-    """This rank's share of ONE (model, n, d) exact-GP matrix.  Every rank constructs one with the same arguments and
-    calls the same methods with the same (replicated) ``X``, ``theta``, ``r``, ``noise``."""
+class TorchComm:
+    """The ranks are the processes of a ``torch.distributed`` group ("nccl" = RCCL over xGMI on a node; gloo in tests).
+    With one rank every collective is skipped unless ``force`` (or ``DGP_DIST_FORCE_COLLECTIVES=1``) asks for it: a
+    world-1 RCCL communicator is legal, and that is how the RCCL entry points of this module are exercised on a
+    one-GPU box."""
 
-    def __init__(self, model: str, n: int, d: int, dtype=torch.float64, device="cuda", rank: int | None = None,
-                 world: int | None = None, group_panels: int = 4, group=None, lookahead: bool = True):
-        mid = model_id(model)
-        if dtype not in _DTYPES:
-            raise ValueError("dtype must be torch.float64 or torch.float32")
-        self.lib = _lib.load()
-        if not torch.cuda.is_available():
-            raise RuntimeError("discontinuum_amd requires a ROCm GPU (MI355X); there is no CPU fallback")
+    def __init__(self, group=None, rank=None, world=None, force=None):
         initialised = dist.is_available() and dist.is_initialized()
         self.group = group
         self.world = int(world) if world is not None else (dist.get_world_size(group) if initialised else 1)
         self.rank = int(rank) if rank is not None else (dist.get_rank(group) if initialised else 0)
         if self.world > 1 and not initialised:
             raise RuntimeError("world > 1 needs an initialised torch.distributed process group")
+        if force is None:
+            force = os.environ.get("DGP_DIST_FORCE_COLLECTIVES", "0") not in ("", "0")
+        self.active = self.world > 1 or (bool(force) and initialised)
+        self.calls = {"broadcast": 0, "all_reduce": 0, "all_gather": 0}  # collectives really issued (tests)
+
+    def _global(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def broadcast(self, buf, owner):
+        """Start the broadcast of ``buf`` from rank ``owner``; -> work handle (``.wait()``) or None."""
+        if not self.active:
+            return None
+        self.calls["broadcast"] += 1
+        return dist.broadcast(buf, src=self._global(owner), group=self.group, async_op=True)
+
+    def all_reduce_sum(self, t):
+        if self.active:
+            self.calls["all_reduce"] += 1
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather(self, t):
+        """-> (world, *t.shape): every rank's ``t``, in rank order."""
+        if not self.active:
+            return t.unsqueeze(0)
+        self.calls["all_gather"] += 1
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.stack(parts)
+
+
+class ThreadComm:
+    """The ranks are THREADS of one process that share one GPU and torch's default stream: a rehearsal communicator for
+    world sizes a one-GPU box cannot host as processes (world = 8 is BASELINE config 5's; the boxes allow six processes
+    per card).  ``ThreadComm.make(world)`` returns one communicator per rank; each rank's thread builds its own
+    ``DistributedFit(..., comm=comms[r])`` and calls the same methods.  Collectives are barriers around device copies on
+    the shared stream -- enqueue order is execution order, so a payload is complete before any rank reads it, and sums
+    run in rank order (every rank gets bitwise the same result)."""
+
+    class _Shared:
+        def __init__(self, world):
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared, rank, world):
+        self._sh, self.rank, self.world = shared, rank, world
+        self.active = world > 1
+        self.calls = {"broadcast": 0, "all_reduce": 0, "all_gather": 0}
+
+    @classmethod
+    def make(cls, world):
+        shared = cls._Shared(world)
+        return [cls(shared, r, world) for r in range(world)]
+
+    def _exchange(self, t):
+        sh = self._sh
+        sh.slots[self.rank] = t
+        sh.barrier.wait()  # every rank's tensor is registered and its producers are enqueued
+        return sh.slots
+
+    def broadcast(self, buf, owner):
+        if not self.active:
+            return None
+        self.calls["broadcast"] += 1
+        slots = self._exchange(buf)
+        if self.rank != owner:
+            buf.copy_(slots[owner])
+        self._sh.barrier.wait()  # every copy is enqueued before the owner may reuse its buffer
+        return None
+
+    def all_reduce_sum(self, t):
+        if not self.active:
+            return t
+        self.calls["all_reduce"] += 1
+        slots = self._exchange(t)
+        total = slots[0].clone()
+        for k in range(1, self.world):
+            total += slots[k]
+        self._sh.barrier.wait()  # every rank has read every contribution
+        t.copy_(total)
+        self._sh.barrier.wait()
+        return t
+
+    def all_gather(self, t):
+        if not self.active:
+            return t.unsqueeze(0)
+        self.calls["all_gather"] += 1
+        slots = self._exchange(t)
+        out = torch.stack([slots[k] for k in range(self.world)])
+        self._sh.barrier.wait()
+        return out
+
+
+def run_thread_ranks(world: int, fn, device=None):
+    """``fn(comm)`` on ``world`` threads, one ``ThreadComm`` rank each -> the results in rank order.  A rank that raises
+    breaks the barrier, so the others fail too instead of waiting for it; the first exception is re-raised."""
+    comms = ThreadComm.make(world)
+    results, errors = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            if device is not None:
+                torch.cuda.set_device(device)
+            results[r] = fn(comms[r])
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+            comms[r]._sh.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,), name=f"dgp-rank-{r}") for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    real = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if real or any(errors):
+        raise (real[0] if real else next(e for e in errors if e is not None))
+    return results
+
+
+class DistributedFit:
+    """This rank's share of ONE (model, n, d) exact-GP matrix.  Every rank constructs one with the same arguments and
+    calls the same methods with the same (replicated) ``X``, ``theta``, ``r``, ``noise``."""
+
+    def __init__(self, model: str, n: int, d: int, dtype=torch.float64, device="cuda", rank: int | None = None,
+                 world: int | None = None, group_panels: int = 4, group=None, lookahead: bool = True, comm=None,
+                 force_collectives: bool | None = None):
+        """``comm``: the communicator (default ``TorchComm`` on ``group`` / the default process group; ``ThreadComm`` for
+        in-process ranks).  ``force_collectives`` (default: environment ``DGP_DIST_FORCE_COLLECTIVES``): issue every
+        collective even with one rank."""
+        mid = model_id(model)
+        if dtype not in _DTYPES:
+            raise ValueError("dtype must be torch.float64 or torch.float32")
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("discontinuum_amd requires a ROCm GPU (MI355X); there is no CPU fallback")
+        self.comm = comm if comm is not None else TorchComm(group, rank, world, force_collectives)
+        self.world, self.rank = self.comm.world, self.comm.rank
         self.model, self.n, self.d, self.dtype, self.device = model, int(n), int(d), dtype, torch.device(device)
         self.lookahead = bool(lookahead)
         h = C.c_void_p()
@@ -68,6 +208,55 @@ class DistributedFit:
             pmax = int(self.lib.dgp_dist_panel_elems(h, 0))
             self._panels = [torch.empty(pmax, dtype=dtype, device=self.device) for _ in range(2)]
         self.alpha = self.dnoise = None
+        self._timing = None
+
+    # ------------------------------------------------------------------ measurement (bench.py --config 5)
+    STAGES = ("gram", "factor", "update", "invert", "pack", "product", "grad")
+    _STAGE_OF = {"dgp_dist_gram": "gram", "dgp_dist_factor": "factor", "dgp_dist_update": "update", "dgp_dist_invert": "invert",
+                 "dgp_dist_pack_inverse": "pack", "dgp_dist_product": "product", "dgp_dist_grad_partial": "grad"}
+
+    def set_timing(self, enabled: bool):
+        """HIP events (torch's, on the stream every ``dgp_dist_*`` kernel is launched on) around each library call of the
+        following fit steps; ``get_timing()`` sums them per stage for the most recent step."""
+        self._timing = {} if enabled else None
+
+    def get_timing(self) -> dict:
+        if self._timing is None:
+            raise RuntimeError("enable timing and run fit_step first")
+        torch.cuda.synchronize(self.device)
+        return {st: sum(a.elapsed_time(b) for a, b in self._timing.get(st, [])) for st in self.STAGES}
+
+    def stage_flops(self) -> dict:
+        """Algorithmic flops THIS rank executes per fit step in each MFMA stage, counted tile by tile exactly as the
+        kernels of csrc/dgp_dist.hip enumerate them (2 m n k per tile product; the owner's panel chain and the diagonal
+        group inverse -- ``factor`` -- are not counted)."""
+        W, nbk, world, rank, N = self.W, self.N // 128, self.world, self.rank, self.N
+        ngl = -(-self.ngroups // world)
+        gblock = lambda lb: ((lb // W) * world + rank) * W + lb % W  # noqa: E731
+        owned_below = lambda g: 0 if g <= rank else (g - rank + world - 1) // world  # noqa: E731
+        tile = 2.0 * 128 * 128
+        fl = {"update": 0.0, "invert": 0.0, "product": 0.0}
+        for g in range(self.ngroups):
+            row0 = (g + 1) * W  # first block row below the group
+            for lb in range(owned_below(g + 1) * W, ngl * W):  # update: own block columns right of g
+                bj = gblock(lb)
+                if bj < nbk:
+                    fl["update"] += (nbk - max(bj, row0)) * tile * 128 * W
+            nbelow = owned_below(g) * W
+            fl["invert"] += nbelow * sum(tile * 128 * (i + 1) for i in range(W))  # T[G, H] = -Linv X[G, H]
+            rows_below = nbk - row0
+            if rows_below > 0:
+                fl["invert"] += rows_below * nbelow * tile * 128 * W
+                if g % world == rank:
+                    fl["invert"] += rows_below * sum(tile * 128 * (W - h) for h in range(W))
+            for lb in range(owned_below(g) * W, ngl * W):  # product: S[group rows, own columns >= the group]
+                bi = gblock(lb)
+                if bi >= nbk:
+                    continue
+                for jq in range(W):
+                    if bi >= g * W + jq:  # tiles on or above the diagonal of S^T (kernel: col_i + BT > col_j)
+                        fl["product"] += tile * (N - bi * 128)
+        return fl
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -86,10 +275,6 @@ class DistributedFit:
     def _owner(self, g: int) -> int:
         return g % self.world
 
-    def _src(self, g: int) -> int:
-        owner = self._owner(g)
-        return dist.get_global_rank(self.group, owner) if self.group is not None else owner
-
     def _payload(self, g: int, with_inverse_block: bool):
         elems = int(self.lib.dgp_dist_panel_elems(self._h, g))
         if not with_inverse_block:
@@ -98,17 +283,21 @@ class DistributedFit:
         return self._panels[g % 2][:elems]
 
     def _broadcast(self, buf, g: int):
-        if self.world == 1:
-            return None
-        return dist.broadcast(buf, src=self._src(g), group=self.group, async_op=True)
+        return self.comm.broadcast(buf, self._owner(g))
 
     def _sum(self, t):
-        if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        return self.comm.all_reduce_sum(t)
 
     def _call(self, name, *args):
+        st = self._STAGE_OF.get(name) if self._timing is not None else None
+        if st is None:
+            _lib.check(getattr(self.lib, name)(self._h, *args, _stream()), name)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
         _lib.check(getattr(self.lib, name)(self._h, *args, _stream()), name)
+        b.record()
+        self._timing.setdefault(st, []).append((a, b))
 
     def set_inputs(self, X: torch.Tensor):
         if not (torch.is_tensor(X) and X.is_cuda and X.dtype == self.dtype and X.is_contiguous() and X.numel() == self.n * self.d):
@@ -130,7 +319,15 @@ class DistributedFit:
     def _pipeline(self, produce, consume):
         """Groups 0 .. ngroups-1 in order: the owner of g runs ``produce(g, payload)``, the payload is broadcast, every
         rank runs ``consume(g, payload, next_group_owned)``; with lookahead the next group is produced and its broadcast
-        started BEFORE the bulk of ``consume(g)``, through ``consume``'s first phase."""
+        started BEFORE the bulk of ``consume(g)``, through ``consume``'s first phase.
+
+        Buffer reuse: payload g lives in ``_panels[g % 2]``, so the broadcast of g + 2 overwrites what ``consume(g)``
+        read.  That is safe only if every access is STREAM-ORDERED before that broadcast: ``produce`` and ``consume``
+        launch on torch's current stream; under "nccl" ``work.wait()`` makes the current stream wait for the collective
+        and the collective's own stream waits for the current stream at the time ``dist.broadcast`` is called
+        (ProcessGroupNCCL semantics) -- which is after ``consume(g)`` was enqueued, because ``start(g + 2)`` is only
+        reached in iteration g + 1.  gloo and ``ThreadComm`` are host-synchronous / same-stream, so the order is
+        trivially kept there; the RCCL ordering has never run on more than one rank (module docstring: UNPINNED)."""
         ng = self.ngroups
         pending = {}
 
@@ -199,16 +396,18 @@ class DistributedFit:
                 raise ValueError(f"{name} must be a contiguous {self.dtype} CUDA tensor with {self.n} elements")
         th = _theta_array(theta, self.ntheta)
         N, n, dt, dev = self.N, self.n, self.dtype, self.device
+        if self._timing is not None:
+            self._timing = {}
         with torch.cuda.device(dev):
             self._factor_and_invert(th, noise)
             stat = torch.empty(2, dtype=dt, device=dev)
             self._call("dgp_dist_status", _ptr(stat))
-            stat64 = stat.double()
-            if self.world > 1:
-                logdet, info = stat64[:1].clone(), stat64[1:].clone()
-                dist.all_reduce(logdet, op=dist.ReduceOp.SUM, group=self.group)
-                dist.all_reduce(info, op=dist.ReduceOp.MAX, group=self.group)
-                stat64 = torch.cat([logdet, info])
+            # ONE gather of the (log-det part, info) pairs: the sum runs in rank order on every rank (bitwise the same
+            # everywhere) and the reported pivot is the FIRST failing one among the ranks' columns
+            allstat = self.comm.all_gather(stat.double())
+            bad_piv = allstat[:, 1]
+            first = torch.where(bad_piv > 0, bad_piv, torch.full_like(bad_piv, float("inf"))).min()
+            stat64 = torch.stack([allstat[:, 0].sum(), torch.where(torch.isinf(first), torch.zeros_like(first), first)])
             z = torch.empty(N, dtype=dt, device=dev)
             self._call("dgp_dist_solve_partial", _ptr(r), _ptr(z))
             self._sum(z)
@@ -224,11 +423,10 @@ class DistributedFit:
             self.alpha, self.dnoise = alpha[:n], None
             if with_grad:
                 self._inverse_products()
-                dtheta = torch.zeros(_lib.OUT_LEN, dtype=dt, device=dev)
-                dnoise = torch.empty(N, dtype=dt, device=dev)
+                tail = torch.zeros(N + _lib.OUT_LEN, dtype=dt, device=dev)  # one all-reduce for both partial results
+                dnoise, dtheta = tail[:N], tail[N:]
                 self._call("dgp_dist_grad_partial", th, _ptr(alpha), _ptr(dtheta), _ptr(dnoise))
-                self._sum(dtheta)
-                self._sum(dnoise)
+                self._sum(tail)
                 out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + self.ntheta] = dtheta[: self.ntheta]
                 out[_lib.OUT_SUM_DR] = alpha[:n].sum()
                 out[_lib.OUT_SUM_DNOISE] = dnoise[:n].sum()

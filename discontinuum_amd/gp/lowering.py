@@ -11,6 +11,8 @@ Anything else (gates, warps, nested sums inside products) raises ``UnsupportedKe
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 
 from . import kernels as K
@@ -166,6 +168,9 @@ def _lower_composite(cov, d):
     return f"composite:{model.value}", theta
 
 
+_WARNED = set()
+
+
 def lower(covar_module, d):
     """-> (model name for ``backend.GPPlan``, zero-argument callable returning theta (P,) float64 with grad)."""
     first = covar_module.kernels[0] if isinstance(covar_module, K.AdditiveKernel) else None
@@ -176,6 +181,12 @@ def lower(covar_module, d):
         return _lower_loadest(covar_module, d)
     except UnsupportedKernelError as fused:
         try:
-            return _lower_composite(covar_module, d)
+            name, theta = _lower_composite(covar_module, d)
+            if name not in _WARNED:  # once per structure: the interpreted evaluator is several times slower per entry
+                _WARNED.add(name)
+                warnings.warn(f"covariance lowered to the generic interpreted evaluator {name!r} -- same kernels and C ABI, "
+                              f"slower Gram / gradient assembly -- because it is not one of the fused models: {fused}",
+                              RuntimeWarning, stacklevel=2)
+            return name, theta
         except UnsupportedKernelError as generic:
             raise UnsupportedKernelError(f"{fused}; and not a generic composite either: {generic}") from None

@@ -1,5 +1,8 @@
 """Resident diagonal-block server (DGP_DIAG_SERVER=1; earlier: the persistent chain kernel of scripts/persistent_chain.patch) against the launch-per-step chain: bitwise comparison of L, L^-1 and the
-result row, then timings.  usage: python scripts/chain_check.py [dtype] [n ...]"""
+result row, then timings.  usage: python scripts/chain_check.py [dtype] [n ...]
+
+PREREQUISITE: libdgp_hip.so built with scripts/diag_server.patch applied -- the shipped library does not read
+DGP_DIAG_SERVER, and without the patch both runs are the same code (the script refuses to run then)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -7,6 +10,8 @@ import bench
 from discontinuum_amd import _lib
 from discontinuum_amd.backend import GPPlan
 
+if b"DGP_DIAG_SERVER" not in open(_lib.LIB_PATH, "rb").read():
+    sys.exit("libdgp_hip.so does not implement DGP_DIAG_SERVER: apply scripts/diag_server.patch and rebuild first")
 dtn = sys.argv[1] if len(sys.argv) > 1 else "f64"
 ns = [int(a) for a in sys.argv[2:]] or [1024, 2048, 4096, 8192]
 dt = torch.float64 if dtn == "f64" else torch.float32

@@ -1,21 +1,28 @@
 #!/bin/bash
 # Collect the round's profiles on the GPU box (run from the repo root through gpurun):
 #   scripts/collect_profiles.sh OUTDIR COMMIT
-# One rocprofv3 pass per counter set (never --pmc together with other trace domains), the program directly after `--`.
+# One rocprofv3 pass per counter set, the program directly after `--`.  Kernel DURATIONS are taken from the `stats`
+# pass only (--kernel-trace --stats, no counters); the --pmc passes also carry --kernel-trace (needed to attribute the
+# counters to kernels; never any other trace domain) and serialise the streams, so their durations are PERTURBED and
+# are not reported as timings anywhere.
 set -o pipefail
 out=${1:-gpurun_out/prof}; commit=${2:-unknown}
-mkdir -p "$out"; cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p "$out"
 run() { name=$1; shift; echo "== $name" >> "$out/log.txt"; timeout -k 10 400 "$@" >> "$out/log.txt" 2>&1 || { echo "FAILED: $name" | tee -a "$out/log.txt"; return 1; }; }
 run stats  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --roofline-only --steps 4 || exit 1
 run fetch  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 bench.py --roofline-only --steps 3 || exit 1
 run write  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -- python3 bench.py --roofline-only --steps 3 || exit 1
 run mfma   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/mfma" -- python3 bench.py --roofline-only --steps 3 || exit 1
-python3 scripts/pmc_summary.py "$out/fetch" "$out/write" "$out/pmc_hbm.json" 3 32 "$commit" > "$out/pmc_hbm.txt" 2>&1
-python3 scripts/mfma_util.py "$out/mfma" "$out/mfma_busy.json" > "$out/mfma_busy.txt" 2>&1
-python3 scripts/trace_summary.py "$out/stats" > "$out/last_step_summary.txt" 2>&1
-python3 scripts/chain_timeline.py "$(ls $out/stats/*/*_kernel_trace.csv | head -1)" > "$out/chain_timeline.txt" 2>&1
-cp "$(ls $out/stats/*/*_kernel_stats.csv | head -1)" "$out/kernel_stats.csv"
-cp "$(ls $out/fetch/*/*_counter_collection.csv | head -1)" "$out/fetch_counter_collection.csv"
-cp "$(ls $out/write/*/*_counter_collection.csv | head -1)" "$out/write_counter_collection.csv"
+ok=1
+python3 scripts/pmc_summary.py "$out/fetch" "$out/write" "$out/pmc_hbm.json" 3 32 "$commit" > "$out/pmc_hbm.txt" 2>&1 || ok=0
+python3 scripts/mfma_util.py "$out/mfma" "$out/mfma_busy.json" > "$out/mfma_busy.txt" 2>&1 || ok=0
+python3 scripts/trace_summary.py "$out/stats" > "$out/last_step_summary.txt" 2>&1 || ok=0
+python3 scripts/chain_timeline.py "$(ls $out/stats/*/*_kernel_trace.csv | head -1)" > "$out/chain_timeline.txt" 2>&1 || ok=0
+cp "$(ls $out/stats/*/*_kernel_stats.csv | head -1)" "$out/kernel_stats.csv" || ok=0
+cp "$(ls $out/fetch/*/*_counter_collection.csv | head -1)" "$out/fetch_counter_collection.csv" || ok=0
+cp "$(ls $out/write/*/*_counter_collection.csv | head -1)" "$out/write_counter_collection.csv" || ok=0
+if [ "$ok" != 1 ]; then echo "a summary step failed: raw rocprofv3 output kept under $out" | tee -a "$out/log.txt"; exit 1; fi
 rm -rf "$out/stats" "$out/fetch" "$out/write" "$out/mfma"
 tail -3 "$out/pmc_hbm.txt"; head -6 "$out/mfma_busy.txt"

@@ -36,3 +36,60 @@ def test_bench_prints_one_contract_line(extra, gpu_device):
     assert len(cpu["steps_s"]) == 2 and cpu["fp32"]["value"] > 0 and cpu["affinity_cores"] >= cpu["cores"]
     assert "configs" not in rec  # only the default n = 8192 run carries the other BASELINE configurations
     assert roof["gram_hbm"]["achieved"] > 0 and roof["gram_grad_hbm"]["achieved"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The driver's multi-GPU command line, rehearsed on the one GPU of the test box: torch.distributed.run starts two ranks
+# (the launcher itself never touches the GPU) that share the card over gloo (DGP_BENCH_BACKEND; RCCL refuses two ranks
+# on one device).  Checks the ONE contract line of rank 0 for both entry points.
+def _torchrun(extra, nproc=2):
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DGP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
+    run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    return json.loads(lines[0])
+
+
+def test_torchrun_two_ranks_headline_line(gpu_device):
+    S = 3
+    rec = _torchrun(["--size", "1024", "--steps", "2", "--warmup", "1", "--sites-per-gpu", str(S)])
+    for key in REQUIRED:
+        assert key in rec, key
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["fits_per_step"] == 2 * S and rec["config"]["sites_per_gpu"] == S
+    assert rec["value"] > 0 and abs(rec["ms_per_step"] * rec["value"] / 1e3 - 2 * S) < 1e-6
+    assert rec["cpu_baseline"] is None  # rank 0 at N = 1 only
+    assert 0 < rec["roofline"]["frac"] < 1
+
+
+def test_torchrun_two_ranks_config5_line(gpu_device):
+    rec = _torchrun(["--config", "5", "--size", "2500", "--dtype", "f32", "--steps", "2", "--warmup", "1"])
+    for key in REQUIRED:
+        assert key in rec, key
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["dtype"] == "f32"
+    assert rec["config"]["info"] == 0 and rec["config"]["backend"] == "gloo"
+    roof = rec["roofline"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["kernel"].startswith("slab_")
+    ng = -(-2500 // 512)
+    assert roof["collectives_issued"] == {"broadcast": 2 * ng, "all_reduce": 3, "all_gather": 1}
+
+
+def test_bench_forced_collectives_enter_rccl_with_one_rank(gpu_device):
+    """`DGP_DIST_FORCE_COLLECTIVES=1 python bench.py --config 5`: one rank, backend nccl, every collective issued."""
+    env = dict(os.environ, DGP_DIST_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DGP_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--size", "3000", "--dtype", "f32", "--steps", "2", "--warmup", "1"]
+    run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    rec = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["config"]["backend"] == "nccl" and rec["config"]["info"] == 0
+    ng = -(-3000 // 512)
+    assert rec["roofline"]["collectives_issued"] == {"broadcast": 2 * ng, "all_reduce": 3, "all_gather": 1}

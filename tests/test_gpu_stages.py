@@ -400,11 +400,20 @@ def test_batched_plan_matches_single_site_plans(model, d, n, B, gpu_device):
             assert (out[b, 4:4 + P] - o1[4:4 + P]).abs().max() <= 1e-10 * o1[4:4 + P].abs().max()
             assert (dr[b] - a1).abs().max() <= 1e-10 * a1.abs().max()
             assert (dn[b] - n1).abs().max() <= 1e-10 * n1.abs().max()
-    # against the oracle for one site, and the single-site-only entry points must refuse a batched plan
+    # against the oracle for one site
     val, g_theta, g_r, _ = orc.nll_data_and_grads(model, *[cases[B - 1][i] for i in (0, 1, 2, 3)])
     assert abs(out[B - 1, 0].cpu() - val) <= 1e-10 * abs(val)
     assert (out[B - 1, 4:4 + g_theta.numel()].cpu() - g_theta).abs().max() <= 1e-8 * max(1.0, g_theta.abs().max().item())
-    with pytest.raises(Exception):
+    # a batched plan predicts every site at its own points (values against the oracle's posterior) ...
+    Xs = torch.stack([make_case(model, d, 5, seed=70 + b)[0] for b in range(B)])
+    mean, var = pb.predict(theta, Xs.to(dev))
+    assert mean.shape == (B, 5) and var.shape == (B, 5)
+    for b in range(B):
+        mu_ref, var_ref = orc.posterior(model, cases[b][0], cases[b][1], cases[b][2], cases[b][3], Xs[b])
+        assert (mean[b].cpu() - mu_ref).abs().max() <= 1e-9
+        assert (var[b].cpu() - var_ref).abs().max() <= 1e-8 * max(1.0, var_ref.abs().max().item())
+    # ... and refuses arguments of a single site's shape
+    with pytest.raises(ValueError):
         pb.predict(theta[0], cases[0][0][:5].to(dev))
 
 
