@@ -226,8 +226,9 @@ def test_world8_thread_ranks_fp32_n16384_match_the_single_plan(gpu_device):
     e_grad = ((g - gr).abs().max() / gr.abs().max()).item()
     e_alpha = (torch.linalg.norm(alpha - ref_a) / torch.linalg.norm(ref_a)).item()
     _record(test="world8_threads_n16384_fp32_vs_single_plan", nll_rel=e_nll, grad_rel=e_grad, alpha_rel=e_alpha)
-    assert e_nll <= 1e-4, e_nll
-    assert e_grad <= 2e-2, e_grad
+    assert e_nll <= 1e-4, e_nll  # measured 2.9e-5
+    assert e_grad <= 3e-4, e_grad  # measured 6.7e-5
+    assert e_alpha <= 6e-3, e_alpha  # measured 1.3e-3
     assert all(torch.equal(o[0], out) for o in res)
 
 
