@@ -432,10 +432,17 @@ __global__ __launch_bounds__(256) void finish_kernel(const T* scal, int* info, l
   }
   __syncthreads();
   if (t == 0) {
-    const T logdet = scal[0], quad = scal[1];
-    out[DGP_OUT_NLL] = T(0.5) * quad + T(0.5) * logdet + T(0.5 * 1.83787706640934548356) * (T)n;
-    out[DGP_OUT_QUAD] = quad;
-    out[DGP_OUT_LOGDET] = logdet;
+    // fp32 plans: the log-determinant (mixed-precision panel, dgp_diag.h) and the quadratic form were accumulated in
+    // double and sit unrounded in the scalar block's double slots (elements 2..3 and 4..5); the three terms of the NLL
+    // -- which cancel to a small number when the noise is small -- are added in double and rounded once
+    double logdet = (double)scal[0], quad = (double)scal[1];
+    if (sizeof(T) == 4) {
+      logdet = *reinterpret_cast<const double*>(scal + 2);
+      quad = *reinterpret_cast<const double*>(scal + 4);
+    }
+    out[DGP_OUT_NLL] = (T)(0.5 * quad + 0.5 * logdet + 0.5 * 1.83787706640934548356 * (double)n);
+    out[DGP_OUT_QUAD] = (T)quad;
+    out[DGP_OUT_LOGDET] = (T)logdet;
     out[DGP_OUT_INFO] = (T)info[0];
   }
   if (zero_grad && t >= DGP_OUT_DTHETA && t < DGP_OUT_LEN) out[t] = T(0);

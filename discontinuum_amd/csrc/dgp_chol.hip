@@ -54,8 +54,7 @@ __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T
 
 // A[i,j] -= sum over panels k..k+nk-1 of A[i,p] A[j,p]^T for the lower tiles with block column >= jbeg
 // (bulk trailing update; nk = 2 halves the passes over the trailing matrix: 53.6 vs 44.5 TFLOP/s in isolation).
-// The accumulators start at -C, so the read of C overlaps the first operand loads and the epilogue
-// is store-only:  C_new = -( -C + P_i P_j^T ).
+// How C joins the accumulators differs by precision: trailing_begin / trailing_end below.
 //
 // All tiles cost the same and the GPU holds 512 of these workgroups at a time, so a launch of t tiles runs in
 // ceil(t / 512) rounds and its last round is on average half empty.  The first `nfull` tiles (whole rounds) are
@@ -67,11 +66,12 @@ __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int
   using G = TileGemm<T, true, true, BM, BN>;
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
-  G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * ld + c]; });
+  typename G::acc_t keep[G::MI][G::NI];
+  trailing_begin<T, G>(acc, keep, C, ld);
   G::template run<(BM == 128 && BN == 128) ? Prefetch<T>::SYRK : 1>(A + row0 * ld + (long)k * NB, ld,
                                                                    A + col0 * ld + (long)k * NB, ld, nk * (NB / 16),
                                                                    smem, acc);
-  G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] = -v; });
+  trailing_end<T, G>(acc, keep, C, ld);
 }
 
 template <typename T>
@@ -137,24 +137,49 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, lon
   if (col0 > row0 + 63) return;  // strictly upper 64x64 quadrant of the diagonal block
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
-  G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * ld + c]; });
+  typename G::acc_t keep[G::MI][G::NI];
+  trailing_begin<T, G>(acc, keep, C, ld);
   G::run(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc);
-  G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * ld + c] = -v; });
+  trailing_end<T, G>(acc, keep, C, ld);
 }
 
-// launch the LDS-resident diagonal-block kernel (needs > 64 KB of dynamic LDS: opt in once per type)
-template <typename T>
-static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hipStream_t s, Batch bt, bool init = false) {
+// launch the LDS-resident diagonal-block kernel (needs > 64 KB of dynamic LDS: opt in once per instantiation).
+// DGP_F32_DIAG64=1 factors the diagonal blocks of fp32 matrices with the MIXED-PRECISION instantiation (block promoted
+// to fp64 in LDS, dgp_diag.h).  Off by default -- measured over 18 matrices (profiles/r03_fp32_error_sources.txt): once
+// the trailing updates sum from zero (dgp_gemm.h::trailing_begin) the fp64 block changes neither the log-determinant
+// nor the quadratic form's error (which is then set by L being STORED in fp32), and costs 2 % (n = 16384) to 12 %
+// (n = 2048) of a fit step.  Kept as a measurement knob.
+static bool f32_diag64() {
+  static const bool v = [] {
+    const char* e = getenv("DGP_F32_DIAG64");
+    return e ? atoi(e) != 0 : false;
+  }();
+  return v;
+}
+template <typename TS, typename TC>
+static void launch_diag_as(TS* A, long N, long k0, TS* Tinv, TS* logdet, int* info, hipStream_t s, Batch bt, bool init,
+                           double* logdet_hi) {
   static bool configured = false;
-  const size_t bytes = potrf_diag_fast_smem<T>();
+  const size_t bytes = potrf_diag_fast_smem<TC>();
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_fast_kernel<T>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_fast_kernel<TS, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     configured = true;
   }
-  potrf_diag_fast_kernel<T><<<dim3(1, 1, (unsigned)bt.B), 256, bytes, s>>>(A, N, k0, Tinv, logdet, info, bt.ws,
-                                                                           bt.ws * (long)sizeof(T) / (long)sizeof(int),
-                                                                           init ? 1 : 0, POTRF_INFO_INTS);
+  potrf_diag_fast_kernel<TS, TC><<<dim3(1, 1, (unsigned)bt.B), 256, bytes, s>>>(
+      A, N, k0, Tinv, logdet, info, bt.ws, bt.ws * (long)sizeof(TS) / (long)sizeof(int), init ? 1 : 0, POTRF_INFO_INTS, logdet_hi);
+}
+// the fp32 plans' unrounded log-determinant lives in the scalar block right behind (log-det, quad): element 2..3 as ONE double
+template <typename T>
+static double* logdet_hi_slot(T* logdet) {
+  return sizeof(T) == 4 ? reinterpret_cast<double*>(logdet + 2) : nullptr;
+}
+template <typename T>
+static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hipStream_t s, Batch bt, bool init = false) {
+  if (sizeof(T) == 4 && f32_diag64())
+    launch_diag_as<T, double>(A, N, k0, Tinv, logdet, info, s, bt, init, logdet_hi_slot(logdet));
+  else
+    launch_diag_as<T, T>(A, N, k0, Tinv, logdet, info, s, bt, init, logdet_hi_slot(logdet));
 }
 
 template <typename T>
@@ -598,16 +623,21 @@ __global__ __launch_bounds__(256) void trmv_t_reduce_kernel(const T* __restrict_
   if (blockIdx.x == gridDim.x - 1) {
     z = site(z, bs);
     quad = site(quad, bs);
-    __shared__ T red[256];
-    T acc = T(0);
-    for (long i = threadIdx.x; i < N; i += 256) acc += z[i] * z[i];
+    // accumulated in double whatever T is (fp32 plans: the sum of up to 2^20 squares would otherwise lose ~3 digits);
+    // fp32 plans also keep the unrounded value in the scalar block's second double slot (quad = scal + 1 -> scal + 4)
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < N; i += 256) acc += (double)z[i] * (double)z[i];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
       if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0) quad[0] = red[0];
+    if (threadIdx.x == 0) {
+      quad[0] = (T)red[0];
+      if (sizeof(T) == 4) *reinterpret_cast<double*>(quad + 3) = red[0];
+    }
     return;
   }
   partial = site(partial, bs);
@@ -776,9 +806,10 @@ __global__ __launch_bounds__(256, 2) void posterior_cov_kernel(const T* __restri
   tri_decode(blockIdx.x, bi, bj);
   typename G::acc_t acc[G::MI][G::NI];
   T* C = cov + (long)bi * NB * M + (long)bj * NB;
-  G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * M + c]; });
+  typename G::acc_t keep[G::MI][G::NI];
+  trailing_begin<T, G>(acc, keep, C, M);
   G::run(V + (long)bi * NB, M, V + (long)bj * NB, M, (int)(N / 16), smem, acc);
-  G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * M + c] = -v; });
+  trailing_end<T, G>(acc, keep, C, M);
 }
 
 template <typename T>

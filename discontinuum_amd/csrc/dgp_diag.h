@@ -149,14 +149,20 @@ __device__ long long dgp_diag_prof[16];
 #define DGP_DIAG_STAMP(i)
 #endif
 
-template <typename T>
-__global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A, long ld, long k0,
-                                                              T* __restrict__ Tinv, T* __restrict__ logdet,
+// TS = the matrix's storage type, T = the type the block is factored and inverted in.  T = TS for fp64 plans; fp32
+// plans use T = double (MIXED-PRECISION PANEL): the block is promoted when it is loaded into LDS, factored and inverted
+// with the fp64 code path (fp64 MFMA, fp64 pivots), and L_kk / L_kk^-1 are rounded to fp32 ONCE when they are stored, so
+// that trsm's operand carries one rounding instead of the ~cond(L_kk) eps32 of an fp32 Gauss-Jordan inverse.  The
+// log-determinant is accumulated in T; `logdet_hi` (the fp32 plans' double slot, may be null) receives it unrounded.
+template <typename TS, typename T = TS>
+__global__ __launch_bounds__(256) void potrf_diag_fast_kernel(TS* __restrict__ A, long ld, long k0,
+                                                              TS* __restrict__ Tinv, TS* __restrict__ logdet,
                                                               int* __restrict__ info, long bs, long ibs, int init,
-                                                              int ninit) {
+                                                              int ninit, double* __restrict__ logdet_hi) {
   A = site(A, bs);
   Tinv = site(Tinv, bs);
   logdet = site(logdet, bs);
+  if (logdet_hi) logdet_hi = (double*)((char*)logdet_hi + (long)blockIdx.z * bs * (long)sizeof(TS));
   info = site(info, ibs);
   // the first diagonal block of a factorisation also resets its status words: info[0] (first bad pivot), the finish
   // kernel's ticket and the early-launch queue counters -- nothing else runs on this matrix yet
@@ -173,8 +179,8 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ti = t >> 4, tj = t & 15;
-  T* Ablk = A + k0 * ld + k0;
-  T* Xblk = Tinv + k0 * ld + k0;
+  TS* Ablk = A + k0 * ld + k0;
+  TS* Xblk = Tinv + k0 * ld + k0;
   // this workgroup usually shares its CU with waves of the bulk trailing update: win the issue arbitration
   __builtin_amdgcn_s_setprio(3);
   DGP_DIAG_STAMP(0)
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
 #pragma unroll
     for (int bi = 0; bi < DGP_DNB; ++bi)
 #pragma unroll
-      for (int bj = 0; bj <= bi; ++bj) tmp[dtri(bi, bj)] = Ablk[(long)(16 * bi + ti) * ld + 16 * bj + tj];
+      for (int bj = 0; bj <= bi; ++bj) tmp[dtri(bi, bj)] = (T)Ablk[(long)(16 * bi + ti) * ld + 16 * bj + tj];
 #pragma unroll
     for (int b = 0; b < DGP_DTRI; ++b) sL[b * DGP_DBLK + ti * DGP_DS + tj] = tmp[b];
   }
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
   for (int bi = 0; bi < DGP_DNB; ++bi)
 #pragma unroll
     for (int bj = 0; bj < DGP_DNB; ++bj)
-      Ablk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = bj <= bi ? sL[dtri(bi, bj) * DGP_DBLK + ti * DGP_DS + tj] : T(0);
+      Ablk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = bj <= bi ? (TS)sL[dtri(bi, bj) * DGP_DBLK + ti * DGP_DS + tj] : TS(0);
 
   DGP_DIAG_STAMP(4)
   // ---- L^-1 by block forward substitution: wave w owns block columns w and 7 - w.  The finished blocks
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
         xb[di - 1] = out;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          Xblk[(long)(16 * i + Mfma<T>::crow(lane, r)) * ld + 16 * j + (lane & 15)] = out[r];
+          Xblk[(long)(16 * i + Mfma<T>::crow(lane, r)) * ld + 16 * j + (lane & 15)] = (TS)out[r];
       }
     }
   }
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
   for (int bi = 0; bi < DGP_DNB; ++bi)
 #pragma unroll
     for (int bj = bi; bj < DGP_DNB; ++bj)
-      Xblk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = bj == bi ? sXd[bi * DGP_DBLK + ti * DGP_DS + tj] : T(0);
+      Xblk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = bj == bi ? (TS)sXd[bi * DGP_DBLK + ti * DGP_DS + tj] : TS(0);
   DGP_DIAG_STAMP(6)
   // ---- log-determinant and first bad pivot (fixed-order tree: reproducible)
   __shared__ T red[128];
@@ -308,7 +314,8 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(T* __restrict__ A,
     __syncthreads();
   }
   if (t == 0) {
-    logdet[0] = init ? red[0] : logdet[0] + red[0];  // diag kernels of one factorisation run in stream order
+    logdet[0] = init ? (TS)red[0] : (TS)((T)logdet[0] + red[0]);  // diag kernels of one factorisation run in stream order
+    if (logdet_hi) logdet_hi[0] = init ? (double)red[0] : logdet_hi[0] + (double)red[0];
     if (bad < 128) atomicCAS(info, 0, (int)(k0 + bad + 1));
   }
   DGP_DIAG_STAMP(7)

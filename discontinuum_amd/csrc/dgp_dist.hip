@@ -68,9 +68,10 @@ __global__ __launch_bounds__(256, 2) void slab_syrk_kernel(T* __restrict__ Aslab
   if (bj >= nbk || bj < cb || bj >= ce || bi < bj) return;
   typename G::acc_t acc[G::MI][G::NI];
   T* C = Aslab + (long)bi * NB * Cl + (long)lb * NB;
-  G::foreach (acc, [&](int r, int c, T& v) { v = -C[(long)r * Cl + c]; });
+  typename G::acc_t keep[G::MI][G::NI];
+  trailing_begin<T, G>(acc, keep, C, Cl);
   G::run(P + ((long)bi * NB - c0) * GW, GW, P + ((long)bj * NB - c0) * GW, GW, GW / 16, smem, acc);
-  G::foreach (acc, [&](int r, int c, T& v) { C[(long)r * Cl + c] = -v; });
+  trailing_end<T, G>(acc, keep, C, Cl);
 }
 
 // T[G, H] = -Linv X[G, H] for the rank's groups H < g: row block i of the group needs X's row blocks <= i (Linv is
@@ -101,10 +102,14 @@ __global__ __launch_bounds__(256, 2) void slab_xacc_kernel(const T* __restrict__
   const long koff = fresh ? (long)h * NB : 0;
   typename G::acc_t acc[G::MI][G::NI];
   T* X = Sslab + (long)bi * NB * Cl + (long)lb * NB;
-  if (fresh) G::zero(acc);
+  // fp32 sums every pass from zero and joins the running sum once (dgp_gemm.h::trailing_begin: K roundings at the
+  // magnitude of the running sum would otherwise swallow the small products)
+  const bool from_zero = fresh || sizeof(T) == 4;
+  if (from_zero) G::zero(acc);
   else G::foreach (acc, [&](int r, int c, T& v) { v = X[(long)r * Cl + c]; });
   G::run(P + ((long)bi * NB - c0) * GW + koff, GW, Tslab + (c0 + koff) * Cl + (long)lb * NB, Cl, (int)((GW - koff) / 16), smem, acc);
-  G::foreach (acc, [&](int r, int c, T& v) { X[(long)r * Cl + c] = v; });
+  if (from_zero && !fresh) G::foreach (acc, [&](int r, int c, T& v) { X[(long)r * Cl + c] += v; });
+  else G::foreach (acc, [&](int r, int c, T& v) { X[(long)r * Cl + c] = v; });
 }
 
 // Pass 2: S[bj, bi] = sum_{c >= bi} T[c, bj]^T T[c, bi] for the rank's block columns bi >= bj, bj in the broadcast group
@@ -188,7 +193,7 @@ __global__ void dist_reset_kernel(T* scal, int* info, int ninfo) {
 }
 template <typename T>
 __global__ void dist_status_kernel(const T* scal, const int* info, T* stat) {
-  stat[0] = scal[0];
+  stat[0] = sizeof(T) == 4 ? (T) * reinterpret_cast<const double*>(scal + 2) : scal[0];  // fp32: the double slot (dgp_diag.h)
   stat[1] = (T)info[0];
 }
 

@@ -80,18 +80,78 @@ def test_rating_fit_objective_predict(gpu_device):
     assert ((var.cpu() - var_ref).abs() / (var_ref.abs() + 1e-4)).max() < 1e-6
 
 
-def test_fp32_engine_runs(gpu_device):
-    """The reference's own dtype (engines/gpytorch.py:221-222): float32 end to end."""
+# float32 at the ENGINE surface -- the reference's only dtype (engines/gpytorch.py:221-222).  Bounds are SURVEY.md section
+# 8d's fp32 row: objective rel 1e-4 max(1, n / 1024), gradients rel 1e-2, posterior mean / variance abs 1e-3 -- against the
+# fp64 oracle evaluated at the model's own (float32-valued) raw parameters and the model's own (float64) data.
+def test_fp32_loadest_engine_matches_the_oracle(gpu_device):
+    from discontinuum_amd.gp.mll import ExactMarginalLogLikelihood
     from discontinuum_amd.loadest_gp import LoadestGP
 
     class LoadestGP32(LoadestGP):
         dtype = torch.float32
 
-    cov, tgt = loadest_dataset(200)
+    torch.manual_seed(0)
+    n = 1200
+    cov, tgt = loadest_dataset(n)
     m = LoadestGP32()
-    m.fit(cov, tgt, iterations=5)
+    m.fit(cov, tgt, iterations=10)
+    assert m.is_fitted and m._train_y.dtype == torch.float32
+    m.model.zero_grad(set_to_none=True)
+    obj = -ExactMarginalLogLikelihood(m.likelihood, m.model)(m._prior(), m._train_y)
+    obj.sum().backward()
+    raw = _loadest_raw_from_model(m).double().clone().requires_grad_(True)
+    X, y = torch.tensor(m.X, dtype=torch.float64), torch.tensor(m.y, dtype=torch.float64)
+    ref = orc.LoadestOracle(2).objective(raw, X, y)
+    ref.backward()
+    assert abs(obj.item() - ref.item()) <= 1e-4 * max(1.0, n / 1024) * abs(ref.item()), (obj.item(), ref.item())
+    got = torch.cat([p.grad.reshape(-1).double() for p in (
+        m.model.mean_module.raw_constant, *[q for q in m.model.covar_module.parameters()])])
+    assert (got - raw.grad).abs().max() / raw.grad.abs().max() <= 1e-2
+    mu_ref, var_ref = orc.LoadestOracle(2).predict(raw.detach(), X, y, X[:400].clone())
+    mu, var = m._model_space_predict(torch.tensor(m.X[:400], dtype=torch.float32))
+    assert mu.dtype == torch.float32
+    assert (mu.cpu().double() - mu_ref).abs().max() <= 1e-3
+    assert (var.cpu().double() - var_ref).abs().max() <= 1e-3
     target, se = m.predict(cov)
-    assert np.all(np.isfinite(target.values))
+    assert np.all(np.isfinite(target.values)) and np.all(se.values >= 1.0)
+
+
+def test_fp32_rating_engine_matches_the_oracle(gpu_device):
+    from discontinuum_amd.gp.lowering import lower
+    from discontinuum_amd.gp.mll import ExactMarginalLogLikelihood
+    from discontinuum_amd.rating_gp import RatingGP
+
+    class RatingGP32(RatingGP):
+        dtype = torch.float32
+
+    torch.manual_seed(1)
+    n = 900
+    cov, tgt, unc = rating_dataset(n)
+    m = RatingGP32()
+    m.fit(cov, tgt, target_unc=unc, iterations=8)
+    m.model.zero_grad(set_to_none=True)
+    obj = -ExactMarginalLogLikelihood(m.likelihood, m.model)(m._prior(), m._train_y)
+    obj.sum().backward()
+    X, y, yu = (torch.tensor(a, dtype=torch.float64) for a in (m.X, m.y, m.y_unc))
+    o = orc.RatingOracle.from_stage(X[:, 1])
+    theta = lower(m.model.covar_module, 2)[1]().detach().double()
+    raw = torch.zeros(20, dtype=torch.float64)
+    raw[0], raw[1], raw[2] = m.model.powerlaw.a.item(), m.model.powerlaw.b.item(), m.model.powerlaw.c.item()
+    raw[3] = m.likelihood.second_noise_covar.raw_noise.item()
+    raw[4] = orc.inv_interval(theta[0], o.b_lo, o.b_hi)
+    raw[5:] = orc.inv_softplus(theta[1:])
+    raw.requires_grad_(True)
+    ref = o.objective(raw, X, y, yu)
+    ref.backward()
+    assert abs(obj.item() - ref.item()) <= 1e-4 * abs(ref.item()) + 1e-5, (obj.item(), ref.item())
+    # the mean's and the learned noise's gradients (host-side parameters fed by the device's dr / dnoise reductions)
+    got = torch.tensor([m.model.powerlaw.a.grad.item(), m.model.powerlaw.b.grad.item(), m.model.powerlaw.c.grad.item(),
+                        m.likelihood.second_noise_covar.raw_noise.grad.item()], dtype=torch.float64)
+    assert (got - raw.grad[:4]).abs().max() <= 1e-2 * raw.grad[:4].abs().max()
+    mu_ref, var_ref = o.predict(raw.detach(), X, y, X[:200].clone(), yu)
+    mu, var = m._model_space_predict(torch.tensor(m.X[:200], dtype=torch.float32))
+    assert (mu.cpu().double() - mu_ref).abs().max() <= 1e-3
+    assert (var.cpu().double() - var_ref).abs().max() <= 1e-3
 
 
 def test_rating_monotonic_penalty_fit(gpu_device):

@@ -7,7 +7,8 @@ the tolerance tied to what fp32 can deliver on THIS matrix: the oracle measures 
     NLL:        |NLL32 - NLL64| / scale              <=  1e-4 max(1, n / 1024)    (SURVEY.md section 8d), scale = the
                 sum of the magnitudes of the NLL's three terms (1/2 quad, 1/2 log-det, n/2 log 2 pi): the log-det of a
                 small-noise matrix is negative and cancels against the other two, so |NLL| itself is not the
-                conditioning scale (measured against |NLL|: loadest 6.7e-6, rating 4.2e-4 at n = 4096)
+                conditioning scale.  BOTH normalisations are asserted (against |NLL|, round 3: loadest 1e-6, rating
+                3e-5 .. 3e-4 over six seeds at n = 4096; before the accumulators started from zero: 4.2e-4)
     gradients:  max |g32 - g64| / max |g64|          <=  1e-2                     
     posterior:  mean abs <= 1e-3, variance abs <= 1e-3                            
 
@@ -68,6 +69,10 @@ def test_fp32_fit_step_and_posterior_against_the_fp64_oracle(model, d, n, gpu_de
     _record(test="fp32_vs_fp64_oracle", model=model, d=d, n=n, cond=cond, nll_rel=e_nll_rel, nll_over_term_scale=e_nll, grad_rel=e_grad, alpha_rel=e_alpha,
             dnoise_rel=e_dnoise, mean_abs=e_mean, var_abs=e_var, alpha_bound=4 * cond * EPS32)
     assert e_nll <= 1e-4 * max(1.0, n / 1024), e_nll
+    # SURVEY.md section 8d's bound as written, against |NLL| itself (restored in round 3: the trailing updates of fp32
+    # plans sum each pass from zero, csrc/dgp_gemm.h::trailing_begin -- before that the log-determinant carried a
+    # systematic +1e-5 n error and this assertion failed at rating n = 4096)
+    assert e_nll_rel <= 1e-4 * max(1.0, n / 1024), e_nll_rel
     assert e_grad <= 1e-2, e_grad
     assert e_alpha <= 4 * cond * EPS32, (e_alpha, cond)
     assert e_dnoise <= 1e-2 + 4 * cond * EPS32, e_dnoise
@@ -77,7 +82,7 @@ def test_fp32_fit_step_and_posterior_against_the_fp64_oracle(model, d, n, gpu_de
 @pytest.mark.parametrize("model,d", [("loadest", 3), ("rating", 2)])
 def test_fp32_batched_and_single_plans_agree_at_n4096(model, d, gpu_device):
     """The same fp32 kernels under the batched schedule (groups of four panels) and the single-site schedule (pairs,
-    early inverse): NLL to 2e-5, alpha to 4 cond eps32 of each other at n = 4096."""
+    early inverse): NLL to 2e-4 (half of SURVEY's fp32 bound at this size), alpha to 2e-2 of each other at n = 4096."""
     from discontinuum_amd import _lib
     from discontinuum_amd.backend import GPPlan
 
@@ -98,5 +103,9 @@ def test_fp32_batched_and_single_plans_agree_at_n4096(model, d, gpu_device):
         e_nll = (abs(out[b, 0] - o1[0]) / abs(o1[0])).item()
         e_alpha = (torch.linalg.norm((dr[b] - a1).double()) / torch.linalg.norm(a1.double())).item()
         _record(test="fp32_batched_vs_single", model=model, n=n, site=b, nll_rel=e_nll, alpha_rel=e_alpha)
-        assert e_nll <= 2e-5, e_nll
+        # two roundings of the same fp64 truth: each schedule is within SURVEY's 1e-4 n / 1024 of it (test above), so they
+        # are within half of that of each other (measured 6e-5 for rating, 1e-6 for loadest).  Until round 3 the two
+        # schedules were bitwise equal in fp32 -- every pass continued ONE fmaf chain started at -C, whatever the group
+        # size -- which is exactly what made the log-determinant drift (csrc/dgp_gemm.h::trailing_begin)
+        assert e_nll <= 2e-4, e_nll
         assert e_alpha <= 2e-2, e_alpha
