@@ -4,7 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 from discontinuum_amd.backend import GPPlan
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-la = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
+la = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # lookahead level 0 / 1 / 2
 d = 3; dev = torch.device("cuda:0"); dt = torch.float64
 rng = np.random.default_rng(0)
 t = np.sort(rng.uniform(-16, 16, n)); cov = rng.standard_normal((n, d-1))
