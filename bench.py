@@ -320,6 +320,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 5],
                     help="2: the headline loop (default); 5: ONE n x n matrix factored and differentiated across all "
                          "ranks (dist_chol.DistributedFit.fit_step; --size 65536 --dtype f32 is BASELINE config 5)")
+    ap.add_argument("--group-panels", type=int, default=0,
+                    help="--config 5: 128-wide panels per column group of the block-cyclic layout (0: DistributedFit's default)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the per-kernel timing loop of the roofline object (the command profiled with "
                          "rocprofv3 --kernel-trace --stats for profiles/)")
@@ -513,7 +515,8 @@ def run_config5(args, model, d, dev, world, rank, dist, barrier, lib):
     dt = torch.float64 if args.dtype == "f64" else torch.float32
     n = args.n
     X, r, noise, theta = site(model, n, d, 0)
-    ctx = dist_chol.DistributedFit(model, n, d, dtype=dt, device=dev, rank=rank, world=world)
+    kw = {"group_panels": args.group_panels} if args.group_panels else {}
+    ctx = dist_chol.DistributedFit(model, n, d, dtype=dt, device=dev, rank=rank, world=world, **kw)
     ctx.set_inputs(torch.tensor(X, dtype=dt, device=dev).contiguous())
     rd, nd = torch.tensor(r, dtype=dt, device=dev), torch.tensor(noise, dtype=dt, device=dev)
     for _ in range(args.warmup):
@@ -554,7 +557,7 @@ def run_config5(args, model, d, dev, world, rank, dist, barrier, lib):
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"ONE {model}-gp matrix n={n} d={d} {args.dtype}: block-cyclic distributed Cholesky, "
                                    f"inverse and gradient over {world} rank(s)", "n": n, "d": d,
-                       "nll": float(host[lib.OUT_NLL]), "info": int(host[lib.OUT_INFO]),
+                       "nll": float(host[lib.OUT_NLL]), "info": int(host[lib.OUT_INFO]), "group_panels": ctx.W,
                        "backend": (dist.get_backend() if dist is not None else None)},
             "job_tflops": float(N) ** 3 * args.steps / elapsed / 1e12,
             "per_rank_hbm_gib": ctx.hbm_bytes() / 2 ** 30, "cpu_baseline": None, "roofline": roofline}))

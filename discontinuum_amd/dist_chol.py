@@ -177,7 +177,7 @@ class DistributedFit:
     calls the same methods with the same (replicated) ``X``, ``theta``, ``r``, ``noise``."""
 
     def __init__(self, model: str, n: int, d: int, dtype=torch.float64, device="cuda", rank: int | None = None,
-                 world: int | None = None, group_panels: int = 4, group=None, lookahead: bool = True, comm=None,
+                 world: int | None = None, group_panels: int | None = None, group=None, lookahead: bool = True, comm=None,
                  force_collectives: bool | None = None):
         """``comm``: the communicator (default ``TorchComm`` on ``group`` / the default process group; ``ThreadComm`` for
         in-process ranks).  ``force_collectives`` (default: environment ``DGP_DIST_FORCE_COLLECTIVES``): issue every
@@ -185,6 +185,11 @@ class DistributedFit:
         mid = model_id(model)
         if dtype not in _DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
+        if group_panels is None:
+            # K = 128 group_panels per read-modify-write pass of the slab GEMMs: measured on one rank at n = 65536 fp32,
+            # 2 / 4 / 8 panels -> 2.73 / 2.50 / 2.36 s per fit step (gpurun_out/r3/c5_w.txt); small matrices keep 4 so that
+            # every rank still owns several groups
+            group_panels = 8 if n >= 32768 else 4
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("discontinuum_amd requires a ROCm GPU (MI355X); there is no CPU fallback")
