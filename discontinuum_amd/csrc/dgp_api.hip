@@ -76,8 +76,9 @@ struct dgp_plan {
   char* ws;
   size_t ws_bytes;
   // carved workspace
-  void *Xt, *A, *Tm, *S, *z, *alpha, *gpart, *spart, *scal;
+  void *Xt, *A, *Tm, *S, *z, *alpha, *gpart, *spart, *scal, *snap;
   int* info;
+  hipStream_t sc;         // rest of the split panel chain (dgp_chol.hip::potrf_split)
   int lookahead, early;   // potrf schedule; issue the inverse's level recursion behind the factorisation's checkpoints
   int have_inputs, have_factor, have_inverse;
   hipStream_t s2, s3;     // bulk trailing updates; early inverse work
@@ -97,7 +98,7 @@ enum { TS_GRAM = 0, TS_POTRF, TS_TRTRI, TS_LAUUM, TS_SOLVE, TS_GRAD, TS_COUNT };
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t Xt, A, Tm, S, z, alpha, gpart, spart, scal, info, total;
+  size_t Xt, A, Tm, S, z, alpha, gpart, spart, scal, info, snap, total;
 };
 static Layout layout(const dgp_plan* p) {
   Layout L;
@@ -113,6 +114,7 @@ static Layout layout(const dgp_plan* p) {
   L.spart = o; o += align_up(e * (size_t)solve_partials(p->N));
   L.scal = o; o += align_up(e * 16);
   L.info = o; o += align_up(sizeof(int) * POTRF_INFO_INTS);
+  L.snap = o; o += align_up(e * 2 * DGP_TILE_HOST * DGP_TILE_HOST);  // the split chain's two snapshot blocks
   L.total = o;
   return L;
 }
@@ -196,6 +198,7 @@ int dgp_plan_destroy(dgp_plan* p) {
     delete[] p->sev;
   }
   if (p->s2) (void)hipStreamDestroy(p->s2);
+  if (p->sc) (void)hipStreamDestroy(p->sc);
   if (p->s3) (void)hipStreamDestroy(p->s3);
   if (p->have_xev)
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(p->xev[i]);
@@ -263,6 +266,7 @@ int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   p->spart = p->ws + L.spart;
   p->scal = p->ws + L.scal;
   p->info = (int*)(p->ws + L.info);
+  p->snap = p->ws + L.snap;
   p->pre = pre_scratch_bytes(p->B) ? (void*)(p->ws + L.total * (size_t)p->B) : nullptr;
   p->nsite = nullptr;
   p->dr_w = nullptr;
@@ -316,13 +320,42 @@ static int ensure_async(dgp_plan* p) {
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   hipError_t e = hipStreamCreateWithPriority(&p->s2, hipStreamNonBlocking, least);
   if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithPriority");
-  p->nev = 2 * (int)(p->N / DGP_TILE_HOST);
+  p->nev = 3 * (int)(p->N / DGP_TILE_HOST);  // group-ahead schedule: P, U; split chain: ED, ER, U
   p->ev = new (std::nothrow) hipEvent_t[p->nev];
   if (!p->ev) return fail(DGP_E_ARG, "out of host memory");
   for (int i = 0; i < p->nev; ++i) {
     e = hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming);
     if (e != hipSuccess) return hipfail(e, "hipEventCreateWithFlags");
   }
+  return 0;
+}
+
+// The split panel chain (critical tile on the caller's stream, rest of the chain on `sc`): one site, pairs of panels,
+// i.e. below the size from which group_size() switches to larger groups because the bulk updates bound the factorisation.
+// DGP_SPLIT_CHAIN=0 selects the single-stream chain (A/B measurements, the bitwise-equality tests); read at every call.
+static bool split_applies(const dgp_plan* p) {
+  const char* e = getenv("DGP_SPLIT_CHAIN");
+  if (e && atoi(e) == 0) return false;
+  const long nbk = p->N / DGP_TILE_HOST;
+  return p->B == 1 && p->lookahead && nbk >= 4 && group_size(p->lookahead, p->B, nbk) == 2;
+}
+// first block column of the split chain: the earliest even k from which a bulk launch (all tiles right of the pair) is at
+// most DGP_SPLIT_TILES tiles (default 768 = 1.5 rounds of the 512 workgroup slots): before that the factorisation is bound
+// by its bulk launches and every chain kernel queues behind them whatever the schedule
+static int split_start(const dgp_plan* p) {
+  const char* e = getenv("DGP_SPLIT_TILES");
+  const long cap = e ? atol(e) : 768;
+  const int nbk = (int)(p->N / DGP_TILE_HOST);
+  int k = 0;
+  while (k + 4 <= nbk && (long)(nbk - k - 3) * (nbk - k - 2) / 2 > cap) k += 2;
+  return k;
+}
+static int ensure_split(dgp_plan* p) {
+  if (!split_applies(p) || p->sc) return 0;
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  hipError_t e = hipStreamCreateWithPriority(&p->sc, hipStreamNonBlocking, greatest);
+  if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithPriority");
   return 0;
 }
 
@@ -478,7 +511,10 @@ template <typename T>
 static int run_potrf(dgp_plan* p, hipStream_t s) {
   int rc = ensure_async(p);
   if (rc) return rc;
-  if ((rc = ensure_timing(p))) return rc;
+  if ((rc = ensure_timing(p)) || (rc = ensure_split(p))) return rc;
+  if (split_applies(p) && p->sc)
+    return potrf_split<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, (T*)p->snap, s, p->sc, p->s2, p->ev,
+                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr, split_start(p));
   return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), s, p->s2, p->ev,
                   p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr,
                   batch_of<T>(p));
@@ -541,9 +577,13 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
                                       EARLY_RESERVED_CUS);
       if (rc && !e->rc) e->rc = rc;
     };
-    if ((rc = ensure_timing(p))) return rc;
-    rc = potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), s, p->s2, p->ev,
-                  p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx);
+    if ((rc = ensure_timing(p)) || (rc = ensure_split(p))) return rc;
+    if (split_applies(p) && p->sc)
+      rc = potrf_split<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, (T*)p->snap, s, p->sc, p->s2, p->ev,
+                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx, split_start(p));
+    else
+      rc = potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), s, p->s2, p->ev,
+                    p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx);
     if (rc || (rc = ctx.rc)) return rc;
     tick(p, TS_POTRF, 1, s);
     tick(p, TS_TRTRI, 0, s);

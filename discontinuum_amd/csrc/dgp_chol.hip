@@ -185,11 +185,11 @@ static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hi
 template <typename T>
 int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
           hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop, int nck, const int* ck_blocks, hipEvent_t* ck_ev,
-          void (*on_ck)(void*, int), void* ck_ctx, Batch bt) {
+          void (*on_ck)(void*, int), void* ck_ctx, Batch bt, int q_stop, PotrfCarry* carry) {
   const int nbk = (int)(N / NB);
   // checkpoint c: recorded on s once the first ck_blocks[c] block columns of L are final (every schedule records
   // every checkpoint, at the latest when the factorisation is complete)
-  int ck_next = 0;
+  int ck_next = carry ? carry->ck_next : 0;
   auto checkpoint = [&](int cols_final) {
     while (ck_next < nck && ck_blocks[ck_next] <= cols_final) {
       hipEventRecord(ck_ev[ck_next], s);
@@ -240,7 +240,10 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     hipEvent_t* P = ev;
     hipEvent_t* U = ev + nbk;
     const int Q = (nbk + G - 1) / G;
-    for (int q = 0; q < Q; ++q) {
+    // q_stop: hand over to the split chain (potrf_split) after chain(q_stop - 1): pair q_stop - 1 is factored, its
+    // updates of the later columns (chain and bulk) are left to the caller, bulk(q_stop - 2) may still be running
+    const int Qrun = (q_stop >= 0 && q_stop < Q) ? q_stop : Q;
+    for (int q = 0; q < Qrun; ++q) {
       const int k0 = G * q, ncol = nbk - k0 < G ? nbk - k0 : G;
       if (q >= 2) hipStreamWaitEvent(s, U[q - 2], 0);  // bulk(q-2) exists whenever chain(q) does
       if (q >= 1)
@@ -267,11 +270,324 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
       }
     }
     // bulk(q) exists for q <= Q-3 and chain(q+2) has waited on every one of them: s is joined
-    checkpoint(nbk);
+    if (Qrun == Q) checkpoint(nbk);
+    if (carry) {
+      carry->ck_next = ck_next;
+      carry->ns = ns;
+      carry->flop = flop;
+    }
     if (n_syrk) *n_syrk = ns;
     if (syrk_flop) *syrk_flop = flop;
     return (int)hipGetLastError();
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// SPLIT PANEL CHAIN (one site, pairs of panels).  The schedule above runs, per panel, diag -> trsm -> column update one
+// after the other on one stream: ~74 us, of which the block kernel is 36.  But the next diagonal block only needs ITS OWN
+// 128 rows of the panel and its own 128 x 128 tile of the update: everything else of trsm / column update is off the
+// critical path.  Here the chain is split over two streams:
+//   critical stream s   crit(k): block (k,k) -= its pending panels (the trsm of its own 128 rows of panel k-1 from a
+//                                SNAPSHOT of those rows + the tile update; for even k also panel k-2, whose rows are final),
+//                                ten small workgroups;   then diag(k)
+//   rest stream c2      R(k):    trsm(k) on all rows below the block (in place), then the column updates of the next
+//                                column(s) -- without the tile crit owns, and leaving a snapshot of the NEXT block's rows
+//                                for crit(k+2) -- and the release of the bulk update of the finished pair
+// with crit(k) waiting for R(k-2) and R(k) for diag(k): R(k-1) and crit(k) + diag(k) overlap.  Every element still
+// receives its panels in ascending order and each pass continues the same k-ordered fma chain, so in fp64 the factor is
+// BITWISE the one of the single-stream schedule (tests/test_gpu_stages.py).
+
+// snapshot[r][c] = A[(row_block 128 + r) ld + col_block 128 + c]  (128 x 128, row stride 128)
+template <typename T>
+__global__ __launch_bounds__(256) void snap_copy_kernel(const T* __restrict__ A, long ld, int row_block, int col_block,
+                                                        T* __restrict__ snap) {
+  const T* src = A + (long)row_block * NB * ld + (long)col_block * NB;
+  for (int i = threadIdx.x + blockIdx.x * 256; i < NB * NB; i += 256 * gridDim.x) snap[i] = src[(long)(i / NB) * ld + i % NB];
+}
+
+// crit(k): the 128 x 128 diagonal block (k,k) receives its pending panels.  Workgroup = one 32 x 32 tile (ti >= tj) of
+// the block, wave = one 16 x 16 sub-block of the tile.
+//   panel k-1:  P = snap X^T with X = L_{k-1,k-1}^-1 (the diagonal block of Tinv), snap = rows of block k of panel k-1
+//               BEFORE their trsm (R(k-1) overwrites them in place meanwhile, with bitwise the same P);
+//   panel k-2 (two_pending): P = A[block k rows, block k-2 columns], final.
+// LDS: X as 36 sub-blocks of 16 x 17 (lower block triangle) + the tile's four 16-row strips of HALF of P (16 sub-blocks).
+template <typename T>
+__global__ __launch_bounds__(256) void crit_kernel(T* __restrict__ A, long ld, int k, const T* __restrict__ Tinv,
+                                                   const T* __restrict__ snap, int nfinal, const int* __restrict__ flags,
+                                                   int need_rest, int need_bulk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char crit_smem[];
+  using acc_t = typename Mfma<T>::acc_t;
+  T* sX = reinterpret_cast<T*>(crit_smem);   // DGP_DTRI sub-blocks
+  T* sP = sX + DGP_DTRI * DGP_DBLK;          // 4 strips x 4 sub-blocks (one half of the panel's columns at a time)
+  int ti, tj;
+  tri_decode((int)blockIdx.x, ti, tj);       // 32 x 32 tile of the block's lower triangle
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int e_r = t >> 4, e_c = t & 15;      // element of a 16 x 16 sub-block this thread stages
+  __builtin_amdgcn_s_setprio(3);
+  // The rest stream's R(k-2) (and, for an even block, the bulk update of pair k/2 - 2) must have finished.  They were
+  // enqueued long before this launch and have normally finished long ago -- an event wait in front of this kernel would
+  // cost the critical stream ~11 us per panel for nothing (measured: profiles/r03_split_chain.txt), so the kernel checks
+  // two counters itself: flags[0] = rest steps finished, flags[1] = bulk launches finished (one-thread signal kernels
+  // behind them).  The producers never depend on anything this kernel does.
+  if (t == 0) {
+    while (__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_rest ||
+           __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_bulk)
+      __builtin_amdgcn_s_sleep(8);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  T* Akk = A + (long)k * NB * ld + (long)k * NB;
+  // strip s (0..3) = 16 rows of the block: strips 0,1 = the tile's rows (ti), strips 2,3 = its columns' rows (tj)
+  const int srow = (wave < 2 ? 2 * ti + wave : 2 * tj + (wave - 2)) * 16;  // first row (inside the block) of this wave's strip
+  // the accumulator: this wave's 16 x 16 sub-block (a, b) of the tile; strictly upper sub-blocks of a diagonal tile are never read
+  const int sa = wave >> 1, sb = wave & 1;
+  const bool live = !(ti == tj && sa < sb);
+  T* Csub = Akk + (long)(32 * ti + 16 * sa) * ld + 32 * tj + 16 * sb;
+  acc_t acc = {T(0), T(0), T(0), T(0)};
+  if (sizeof(T) == 8 && live)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Csub[(long)Mfma<T>::crow(lane, r) * ld + (lane & 15)];
+  // ---- everything this kernel reads from global memory is requested up front
+  // nfinal = panels whose rows of this block are FINAL in A (0: odd block, 1: even block -- panel k-2 --, 2: the first
+  // block after the hand-over from the pair schedule, whose panel k-1 was solved there: no snapshot, no trsm here)
+  const bool solve = nfinal < 2;
+  T xreg[DGP_DTRI];  // X = L_{k-1,k-1}^-1, lower block triangle
+  T af[DGP_DNB][4];  // this wave's 16 rows of the snapshot as MFMA A fragments
+  if (solve) {
+    const T* Xg = Tinv + (long)(k - 1) * NB * ld + (long)(k - 1) * NB;
+#pragma unroll
+    for (int bi = 0; bi < DGP_DNB; ++bi)
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj) xreg[dtri(bi, bj)] = Xg[(long)(16 * bi + e_r) * ld + 16 * bj + e_c];
+#pragma unroll
+    for (int kc = 0; kc < DGP_DNB; ++kc)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) af[kc][ks] = snap[(long)(srow + (lane & 15)) * NB + 16 * kc + 4 * ks + (lane >> 4)];
+  }
+  // The panel's 128 columns are processed in two halves (LDS: X + 4 strips x 4 sub-blocks = 113 KB in fp64, so that the
+  // workgroup fits on a CU beside ONE bulk workgroup: with 148 KB it could only start once a whole CU had drained and
+  // starved behind a saturating bulk launch -- measured 277 us instead of 15).
+  auto apply = [&](int half) {  // acc -= P[strip sa of ti] P[strip sb of tj]^T over columns 64 half .. 64 half + 63, ascending
+    if (!live) return;
+    const T* Pi = sP + (sa)*4 * DGP_DBLK;
+    const T* Pj = sP + (2 + sb) * 4 * DGP_DBLK;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const T a = frag_rc(Pi + kb * DGP_DBLK, ks, lane), b = frag_rc(Pj + kb * DGP_DBLK, ks, lane);
+        acc = sizeof(T) == 8 ? Mfma<T>::mma(-a, b, acc) : Mfma<T>::mma(a, b, acc);  // fp32: summed from zero, joined below
+      }
+    (void)half;
+  };
+  for (int f = 0; f < nfinal; ++f) {  // panels k-2 (, k-1): final rows of L, this wave's strip straight into LDS (lane = one column of a half)
+    const T* Pg = A + ((long)k * NB + srow) * ld + (long)(k - 2 + f) * NB + lane;
+    T pr[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) pr[h][rr] = Pg[(long)rr * ld + 64 * h];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) sP[(wave * 4 + (lane >> 4)) * DGP_DBLK + rr * DGP_DS + (lane & 15)] = pr[h][rr];
+      __syncthreads();
+      apply(h);
+      __syncthreads();
+    }
+  }
+  if (solve) {
+  // ---- panel k-1: X into LDS
+#pragma unroll
+  for (int b = 0; b < DGP_DTRI; ++b) sX[b * DGP_DBLK + e_r * DGP_DS + e_c] = xreg[b];
+  __syncthreads();
+  // P[strip, jb] = sum_{kc <= jb} snap[strip, kc] X[jb, kc]^T   (k ascending: the order of trsm_kernel's chain; the
+  // zero blocks kc > jb add nothing)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      const int jb = 4 * h + j4;
+      acc_t p = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int kc = 0; kc <= jb; ++kc)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) p = Mfma<T>::mma(af[kc][ks], frag_rc(sX + dtri(jb, kc) * DGP_DBLK, ks, lane), p);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sP[(wave * 4 + j4) * DGP_DBLK + Mfma<T>::crow(lane, r) * DGP_DS + (lane & 15)] = p[r];
+    }
+    __syncthreads();
+    apply(h);
+    __syncthreads();
+  }
+  }
+  if (live)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T* c = &Csub[(long)Mfma<T>::crow(lane, r) * ld + (lane & 15)];
+      *c = sizeof(T) == 8 ? acc[r] : *c - acc[r];
+    }
+}
+__global__ void chain_signal_kernel(int* word, int value) {
+  if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+static size_t crit_smem_bytes() { return (size_t)(DGP_DTRI + 16) * DGP_DBLK * sizeof(T); }
+
+// Column updates of the rest stream: up to two jobs per launch (blockIdx.z), each one block column jc receiving panels
+// k .. k + nk - 1 on its rows from block row_lo down (row_lo = jc: with the diagonal block; jc + 1: without -- crit owns
+// it), 64 x 64 tiles like syrk_col_kernel.  Tiles of block row snap_rb are also stored to `snap` (the rows the next
+// crit kernel will solve itself).
+struct ChainJob {
+  int jc, row_lo, k, nk, snap_rb;
+};
+struct ChainJobs {
+  ChainJob j[2];
+};
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chain_col_kernel(T* __restrict__ A, long ld, int nbk, ChainJobs jobs,
+                                                           T* __restrict__ snap) {
+  using G = TileGemm<T, true, true, 64, 64>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  __builtin_amdgcn_s_setprio(3);
+  const ChainJob jb = jobs.j[blockIdx.z];
+  const long row0 = (long)jb.row_lo * NB + (long)blockIdx.x * 64;
+  if (row0 >= (long)nbk * NB) return;
+  const long col0 = (long)jb.jc * NB + (long)blockIdx.y * 64;
+  if (col0 > row0 + 63) return;  // strictly upper 64 x 64 quadrant of the diagonal block
+  typename G::acc_t acc[G::MI][G::NI];
+  T* C = A + row0 * ld + col0;
+  typename G::acc_t keep[G::MI][G::NI];
+  trailing_begin<T, G>(acc, keep, C, ld);
+  G::run(A + row0 * ld + (long)jb.k * NB, ld, A + col0 * ld + (long)jb.k * NB, ld, jb.nk * (NB / 16), smem, acc);
+  trailing_end<T, G>(acc, keep, C, ld);
+  if (jb.snap_rb >= 0 && row0 / NB == jb.snap_rb) {
+    T* sn = snap + (row0 - (long)jb.snap_rb * NB) * NB + (long)blockIdx.y * 64;
+    G::foreach (acc, [&](int r, int c, T& v) { sn[(long)r * NB + c] = sizeof(T) == 8 ? -v : v; });
+  }
+}
+
+// k_start (even): the block columns before it are factored by the single-stream pair schedule (potrf with q_stop) --
+// while a bulk launch is many rounds long the factorisation is bound by it, and crit's ten workgroups would queue behind
+// it like every other chain kernel -- and the split chain takes over from there.
+template <typename T>
+int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_t s, hipStream_t c2, hipStream_t s2,
+                hipEvent_t* ev /* 3 nbk */, hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop, int nck, const int* ck_blocks,
+                hipEvent_t* ck_ev, void (*on_ck)(void*, int), void* ck_ctx, int k_start) {
+  const int nbk = (int)(N / NB);
+  if (k_start < 0) k_start = 0;
+  k_start &= ~1;
+  if (k_start + 4 > nbk)  // nothing left for the split chain
+    return potrf<T>(A, N, Tinv, logdet, info, 2, s, s2, ev, syrk_ev, n_syrk, syrk_flop, nck, ck_blocks, ck_ev, on_ck, ck_ctx);
+  PotrfCarry carry;
+  const Batch bt;
+  hipEvent_t* ED = ev;            // diag(k) done, on s
+  hipEvent_t* ER = ev + nbk;      // R(k) done, on c2
+  hipEvent_t* U = ev + 2 * nbk;   // bulk(q) done, on s2
+  static bool configured[2] = {false, false};
+  const size_t cbytes = crit_smem_bytes<T>();
+  if (!configured[sizeof(T) == 8]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&crit_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbytes);
+    configured[sizeof(T) == 8] = true;
+  }
+  int ck_next = 0;
+  int ns = 0, last_u = -1;
+  double flop = 0.0;
+  int* flags = info + CHAIN_FLAG0;  // zeroed with the other status words by the first diagonal-block kernel
+  if (k_start > 0) {
+    const int q0 = k_start / 2;
+    const int rc = potrf<T>(A, N, Tinv, logdet, info, 2, s, s2, ev, syrk_ev, n_syrk, syrk_flop, nck, ck_blocks, ck_ev, on_ck,
+                            ck_ctx, Batch(), q0, &carry);
+    if (rc) return rc;
+    ck_next = carry.ck_next;
+    ns = carry.ns;
+    flop = carry.flop;
+  }
+  auto checkpoint = [&](int cols_final, hipStream_t st) {
+    while (ck_next < nck && ck_blocks[ck_next] <= cols_final) {
+      hipEventRecord(ck_ev[ck_next], st);
+      if (on_ck) on_ck(ck_ctx, ck_next);
+      ++ck_next;
+    }
+  };
+  auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
+  const double tile_flop = 2.0 * NB * NB * NB;
+  auto bulk_exists = [&](int q) { return q >= 0 && 2 * q + 4 < nbk; };
+  auto bulk = [&](int q) {  // block columns >= 2q + 4 <- pair q, behind the rest step recorded in ER[2q + 1]
+    const int k = 2 * q + 1;
+    hipStreamWaitEvent(s2, ER[k], 0);
+    if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
+    const SyrkShape sh((int)tri(nbk - k - 3), 512);
+    syrk_kernel<T><<<dim3(sh.grid, 1, 1), 256, 0, s2>>>(A, N, k - 1, 2, k + 3, sh.nfull, sh.split, 0);
+    if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
+    flop += 2.0 * tile_flop * tri(nbk - k - 3);
+    ++ns;
+    chain_signal_kernel<<<1, 64, 0, s2>>>(flags + 1, q + 1);  // bulk(q) finished
+    hipEventRecord(U[q], s2);
+    last_u = q;
+  };
+  if (k_start == 0) {
+    snap_copy_kernel<T><<<8, 256, 0, s>>>(A, N, 1, 0, snap + (long)NB * NB);  // rows of block 1 of panel 0, before their trsm
+  } else {
+    // hand-over from the pair schedule after chain(q0 - 1): what R(k_start - 1) would have done except its trsm -- the
+    // chain's own two columns <- pair q0 - 1, the snapshot for crit(k_start + 1) -- then the counters and bulk(q0 - 1)
+    const int k = k_start - 1, q0 = k_start / 2;
+    hipEvent_t* Uold = ev + nbk;  // the pair schedule's U events (its P events are ev[0 .. q0))
+    hipEventRecord(ED[k_start], s);  // any free slot of ED: the chain of the pair schedule ends here
+    hipStreamWaitEvent(c2, ED[k_start], 0);
+    if (q0 >= 2) {
+      hipStreamWaitEvent(c2, Uold[q0 - 2], 0);
+      hipStreamWaitEvent(s2, Uold[q0 - 2], 0);
+    }
+    ChainJobs jobs;
+    jobs.j[0] = ChainJob{k + 1, k + 2, k - 1, 2, k + 2};
+    jobs.j[1] = ChainJob{k + 2, k + 2, k - 1, 2, -1};
+    chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 2), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB);
+    chain_signal_kernel<<<1, 64, 0, c2>>>(flags, k + 1);
+    hipEventRecord(ER[k], c2);
+    chain_signal_kernel<<<1, 64, 0, s2>>>(flags + 1, q0 - 1);  // the pair schedule's bulk launches (0 .. q0 - 2) are through
+    if (k + 3 < nbk) bulk(q0 - 1);
+  }
+  for (int k = k_start; k < nbk; ++k) {
+    // ---- critical stream
+    if (k >= 1) {
+      // crit(k) needs R(k-2) and, for an even block, bulk(k/2 - 2): checked inside the kernel (flags), not by stream waits
+      const int need_rest = k >= 2 ? k - 1 : 0, need_bulk = ((k & 1) == 0 && k >= 4 && bulk_exists(k / 2 - 2)) ? k / 2 - 1 : 0;
+      const int nfinal = (k & 1) ? 0 : ((k == k_start && k_start > 0) ? 2 : 1);
+      crit_kernel<T><<<10, 256, cbytes, s>>>(A, N, k, Tinv, snap + (long)(k & 1) * NB * NB, nfinal, flags, need_rest, need_bulk);
+    }
+    launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt, k == 0);
+    if (k + 1 >= nbk) break;
+    hipEventRecord(ED[k], s);
+    // ---- rest stream
+    hipStreamWaitEvent(c2, ED[k], 0);
+    trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, 1), 256, 0, c2>>>(A, Tinv, N, k, 0);
+    const int q = k >> 1;
+    ChainJobs jobs;
+    if ((k & 1) == 0) {  // first panel of pair q: column k+1 (below its diagonal block) <- panel k; snapshot block row k+2
+      jobs.j[0] = ChainJob{k + 1, k + 2, k, 1, k + 2};
+      jobs.j[1] = jobs.j[0];
+      if (k + 2 < nbk)
+        chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 1), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB);
+    } else {             // second panel: columns k+1 (below its diagonal block; snapshot block row k+2) and k+2 (whole) <- pair q
+      if (q >= 1) hipStreamWaitEvent(c2, U[q - 1], 0);
+      jobs.j[0] = ChainJob{k + 1, k + 2, k - 1, 2, k + 2};
+      jobs.j[1] = ChainJob{k + 2, k + 2, k - 1, 2, -1};
+      if (k + 2 < nbk)
+        chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 2), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB);
+    }
+    chain_signal_kernel<<<1, 64, 0, c2>>>(flags, k + 1);  // R(k) finished
+    hipEventRecord(ER[k], c2);
+    checkpoint(k + 1, c2);
+    if ((k & 1) == 1 && k + 3 < nbk) bulk(q);  // released behind the chain's own updates
+  }
+  // every R(k) was waited for by crit(k+2) except the last one; every bulk launch by the crit of a later even block or not at all
+  if (nbk >= 2) hipStreamWaitEvent(s, ER[nbk - 2], 0);
+  if (last_u >= 0) hipStreamWaitEvent(s, U[last_u], 0);  // s2 runs its launches in order
+  checkpoint(nbk, s);
+  if (n_syrk) *n_syrk = ns;
+  if (syrk_flop) *syrk_flop = flop;
+  return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -853,7 +1169,9 @@ int sample_draws(const T* L, long M, const T* Z, long Q, const T* mean, int m, i
   template int sample_draws<T>(const T*, long, const T*, long, const T*, int, int, T*, hipStream_t);             \
   template int symv_lower<T>(const T*, long, const T*, int, const T*, T*, T*, T*, hipStream_t);                  \
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \
-                        const int*, hipEvent_t*, void (*)(void*, int), void*, Batch);                                                                                        \
+                        const int*, hipEvent_t*, void (*)(void*, int), void*, Batch, int, PotrfCarry*);                                                                                        \
+  template int potrf_split<T>(T*, long, T*, T*, int*, T*, hipStream_t, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, \
+                              int, const int*, hipEvent_t*, void (*)(void*, int), void*, int);                       \
   template int potrf_group<T>(T*, long, int, T*, T*, int*, int, int, hipStream_t);                                \
   template int trtri_advance<T>(const T*, long, T*, T*, int, TrtriProgress*, hipStream_t, int, int*, int, int, Batch, long);                   \
   template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t, Batch, long);                                        \

@@ -48,12 +48,24 @@ template <typename T>
 int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream_t s);  // number of T elements `partials` must hold
 
 // ---- dgp_chol.hip ---------------------------------------------------------------------------
+struct PotrfCarry {  // state of a factorisation that one schedule hands to the next (potrf with q_stop -> potrf_split)
+  int ck_next = 0, ns = 0;
+  double flop = 0.0;
+};
 template <typename T>
 int potrf(T* A, long N, T* Dinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
           hipEvent_t* syrk_ev /* 2 per bulk launch, or null */, int* n_syrk, double* syrk_flop,
           int nck = 0, const int* ck_blocks = nullptr /* ascending */, hipEvent_t* ck_ev = nullptr,
           void (*on_ck)(void* ctx, int idx) = nullptr /* called right after checkpoint idx is recorded */,
-          void* ck_ctx = nullptr, Batch bt = Batch());
+          void* ck_ctx = nullptr, Batch bt = Batch(), int q_stop = -1 /* stop after chain(q_stop - 1): potrf_split */,
+          struct PotrfCarry* carry = nullptr);
+// the split panel chain (one site, fewer than 96 block columns): critical tile on `s`, rest of the chain on `c2`,
+// bulk updates on `s2`; ev holds 3 N/128 events; snap = 2 x 128 x 128 elements of workspace
+template <typename T>
+int potrf_split(T* A, long N, T* Dinv, T* logdet, int* info, T* snap, hipStream_t s, hipStream_t c2, hipStream_t s2,
+                hipEvent_t* ev, hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop, int nck = 0,
+                const int* ck_blocks = nullptr, hipEvent_t* ck_ev = nullptr, void (*on_ck)(void* ctx, int idx) = nullptr,
+                void* ck_ctx = nullptr, int k_start = 0 /* even: block columns before it by the single-stream schedule */);
 // progress of the level recursion of trtri when it is issued piecewise (trtri_advance)
 struct TrtriProgress {
   static constexpr int MAXLVL = 16;
@@ -65,6 +77,7 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready_blocks, TrtriProgre
                   int* ctr /* info + EARLY_CTR0, or null */, int nctr_pairs, int reserve_cus, Batch bt = Batch(),
                   long ld = 0 /* leading dimension of L, Tm, W if not N */);
 // info[0] = potrf status; info[EARLY_CTR0 + 2i ..] = (tile queue, worker count) of the i-th early inverse launch
+#define CHAIN_FLAG0 2  /* info[2], info[3]: the split chain's progress counters (rest steps / bulk launches finished) */
 #define EARLY_CTR0 4
 #define EARLY_CTR_PAIRS 126
 #define POTRF_INFO_INTS (EARLY_CTR0 + 2 * EARLY_CTR_PAIRS)

@@ -303,6 +303,70 @@ def test_early_inverse_matches_in_order_schedule(n, gpu_device):
     assert (S2 @ (Khat @ probe) + torch.tril(S2, -1).T @ (Khat @ probe) - probe).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("model,d,n,split_tiles", [("loadest", 3, 500, None), ("loadest", 3, 512, None), ("rating", 2, 640, None),
+                                                   ("loadest", 3, 1000, None), ("loadest", 2, 2048, None), ("rating", 2, 3300, None),
+                                                   # hand-over from the pair schedule to the split chain after 2, 6, 12 pairs
+                                                   ("loadest", 3, 2500, 120), ("loadest", 3, 3300, 60), ("rating", 2, 3072, 21)])
+def test_split_panel_chain_is_bitwise_the_single_stream_chain(model, d, n, split_tiles, gpu_device, monkeypatch):
+    """The split panel chain (critical tile on the caller's stream, rest of the chain on a second stream, in-kernel progress
+    counters; csrc/dgp_chol.hip::potrf_split) applies every panel to every element in the same order and continues the same
+    k-ordered fma chains as the single-stream schedule: L, L^-1 and the whole result row are BITWISE equal in fp64, also
+    when the factorisation starts in the pair schedule and hands over (DGP_SPLIT_TILES moves the switch point), at every
+    lookahead level, and run to run."""
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=n, perturb=0.1)
+    if split_tiles is not None:
+        monkeypatch.setenv("DGP_SPLIT_TILES", str(split_tiles))
+    res = {}
+    for mode, level in (("0", 1), ("1", 1), ("1", 2), ("1", 1)):
+        monkeypatch.setenv("DGP_SPLIT_CHAIN", mode)
+        p = plan_for(model, d, n, X, torch.float64, dev, lookahead=level)
+        out, dr, dn = p.fit_step(theta, r.to(dev), noise.to(dev))
+        torch.cuda.synchronize()
+        got = (out.cpu(), tril_n(p.buffer(_lib.BUF_A), n).clone(), tril_n(p.buffer(_lib.BUF_T), n).clone())
+        if (mode, level) in res:  # the repeated configuration: bitwise run to run
+            assert all(torch.equal(a, b) for a, b in zip(got, res[(mode, level)]))
+        res[(mode, level)] = got
+        del p
+    ref = res[("0", 1)]
+    assert ref[0][_lib.OUT_INFO] == 0
+    for key in (("1", 1), ("1", 2)):
+        out, L, Tm = res[key]
+        assert torch.equal(L, ref[1]), key
+        assert torch.equal(Tm, ref[2]), key
+        assert torch.equal(out[:4], ref[0][:4]), key  # NLL, quad, log-det, info
+    val, g_theta, _, _ = orc.nll_data_and_grads(model, X, r, noise, theta)
+    assert abs(ref[0][0] - val) <= 1e-10 * abs(val)
+
+
+def test_split_panel_chain_fp32_and_not_positive_definite(gpu_device, monkeypatch):
+    """fp32 through the split chain (its trailing updates sum from zero, so schedules differ by rounding, not bitwise):
+    both schedules within SURVEY's fp32 bound of the fp64 oracle; and a non-PD matrix is reported, not hung on."""
+    from discontinuum_amd import _lib
+
+    dev, n = gpu_device, 3000
+    X, r, noise, theta = make_case("loadest", 3, n, seed=5, perturb=0.1)
+    val = orc.nll_data_and_grads("loadest", X, r, noise, theta)[0]
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DGP_SPLIT_CHAIN", mode)
+        p = plan_for("loadest", 3, n, X, torch.float32, dev)
+        out = p.fit_step(theta, r.float().to(dev), noise.float().to(dev))[0].cpu().double()
+        assert out[_lib.OUT_INFO] == 0 and abs(out[0] - val) <= 1e-4 * (n / 1024) * abs(val), mode
+        del p
+    monkeypatch.setenv("DGP_SPLIT_CHAIN", "1")
+    Xb = X.clone()
+    Xb[1700] = Xb[300]
+    bad = noise.clone()
+    bad[300] = bad[1700] = -0.5
+    p = plan_for("loadest", 3, n, Xb, torch.float64, dev)
+    out = p.fit_step(theta, r.to(dev), bad.to(dev))[0].cpu()
+    assert out[_lib.OUT_INFO] >= 1 and not torch.isfinite(out[_lib.OUT_NLL])
+    out = p.fit_step(theta, r.to(dev), noise.to(dev))[0].cpu()  # the next step on the same plan recovers
+    assert out[_lib.OUT_INFO] == 0 and torch.isfinite(out[_lib.OUT_NLL])
+
+
 @pytest.mark.parametrize("model,d,n", [("loadest", 2, 1), ("loadest", 2, 2), ("loadest", 3, 17), ("loadest", 2, 127),
                                        ("loadest", 3, 128), ("loadest", 2, 129), ("rating", 2, 3), ("rating", 2, 257)])
 def test_edge_sizes_fp64(model, d, n, gpu_device):
