@@ -307,21 +307,26 @@ class GPPlan:
         return mean
 
     def mean_vjp(self, theta, Xs: torch.Tensor, w: torch.Tensor):
-        """Vector-Jacobian product of ``predict_mean``: (dtheta[P], dr[n], dnoise[n]) for upstream w[m]."""
-        th = _theta_array(theta, self.ntheta)
-        m = Xs.shape[0]
+        """Vector-Jacobian product of ``predict_mean``: (dtheta[P], dr[n], dnoise[n]) for upstream w[m].  Batched plans:
+        Xs (batch, m, d), w (batch, m) -> dtheta (batch, P), dr (batch, n), dnoise (batch, n), one launch sequence for all sites."""
+        th = _theta_array(theta, self.ntheta * self.batch)
+        lead = () if self.batch == 1 else (self.batch,)
+        if Xs.dim() != 2 + len(lead) or tuple(Xs.shape[:-2]) != lead or Xs.shape[-1] != self.d:
+            raise ValueError(f"Xs must have shape {lead + ('m', self.d)}")
+        m = Xs.shape[-2]
         self._check_vec(w, "w", m)
         with torch.cuda.device(self.device):
             xs = Xs.contiguous()
             work, need = self._vjp_workspace(m)
-            dtheta = torch.zeros(_lib.OUT_LEN, dtype=self.dtype, device=self.device)
-            dr = torch.empty(self.n, dtype=self.dtype, device=self.device)
-            dnoise = torch.empty(self.n, dtype=self.dtype, device=self.device)
+            width = _lib.OUT_LEN if self.batch == 1 else self.ntheta
+            dtheta = torch.zeros(lead + (width,), dtype=self.dtype, device=self.device)
+            dr = torch.empty(lead + (self.n,), dtype=self.dtype, device=self.device)
+            dnoise = torch.empty(lead + (self.n,), dtype=self.dtype, device=self.device)
             _lib.check(
                 self.lib.dgp_mean_vjp(self._h, th, _ptr(xs), m, _ptr(w), work, need, _ptr(dtheta), _ptr(dr), _ptr(dnoise), _stream()),
                 "dgp_mean_vjp",
             )
-        return dtheta[: self.ntheta], dr, dnoise
+        return dtheta[..., : self.ntheta], dr, dnoise
 
     def potrf_info(self) -> int:
         """info of the last factorisation (0 = ok, k = first non-positive pivot), synchronising."""

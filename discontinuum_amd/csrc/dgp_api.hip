@@ -482,13 +482,6 @@ __global__ __launch_bounds__(256) void finish_kernel(const T* scal, int* info, l
   if (!zero_grad && t >= DGP_OUT_DTHETA + ntheta && t < DGP_OUT_LEN) out[t] = t >= DGP_OUT_SUM_DR ? red[0][t - DGP_OUT_SUM_DR] : T(0);
 }
 
-template <typename T>
-__global__ void copy_n_kernel(const T* src, long n, T* dst, long bs) {
-  src = site(src, bs);
-  dst = site(dst, n);
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = src[i];
-}
 
 template <typename T>
 static Batch batch_of(const dgp_plan* p) {
@@ -625,19 +618,52 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
   return (int)hipGetLastError();
 }
 
+// ---- inference on the factorisation a plan holds.  Batched plans run every launch once for all sites (gridDim.z =
+// sites, like the fit step): the caller's work area holds one slice per site (site stride = the single-site size).
+static size_t predict_site_bytes(const dgp_plan* p, int64_t m) {
+  const size_t M = (size_t)round_up(m, DGP_TILE_HOST), e = p->elem;
+  return align_up(e * M * p->d) + 2 * align_up(e * (size_t)p->N * M) + 3 * align_up(e * M) + align_up(e * 2 * PREDICT_SPLIT * M);
+}
+// hyperparameters of a batch of more than 8 sites travel through the plan's device scratch + a pinned staging slot
+struct PreSlot {
+  dgp_plan* p;
+  void* staging;
+  hipStream_t s;
+  PreSlot(dgp_plan* plan, hipStream_t st) : p(plan), staging(plan->pre ? plan->ring.acquire(pre_scratch_bytes(plan->B)) : nullptr), s(st) {
+    plan->pre_ready = 0;  // the fit step's copy of the hyperparameters is overwritten
+  }
+  ~PreSlot() {
+    if (staging) p->ring.commit(s);
+  }
+};
+
 template <typename T>
-static int cross(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* Ks, hipStream_t s) {
+static int cross(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* Ks, hipStream_t s, long wbs = 0) {
   const long M = round_up(m, DGP_TILE_HOST);
-  int rc = pack_x<T>((const T*)Xs, (int)m, p->d, M, (T*)work, s);
+  Batch wb;  // the test points: [B][m][d] -> SoA in the work area
+  wb.B = p->B;
+  wb.ws = wbs;
+  int rc = pack_x<T>((const T*)Xs, (int)m, p->d, M, (T*)work, s, wb);
   if (rc) return rc;
-  return gram_cross<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, (const T*)work, M, (int)m, theta, (T*)Ks, s);
+  PreSlot slot(p, s);
+  return gram_cross<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, (const T*)work, M, (int)m, theta, (T*)Ks, s, batch_of<T>(p), wbs,
+                       p->pre, slot.staging);
 }
 
 template <typename T>
-static int predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* mean, void* var,
-                   hipStream_t s) {
+__global__ void copy_rows_kernel(const T* src, long n, T* dst, long src_stride) {  // dst [site][n] <- src at src_stride
+  src = site(src, src_stride);
+  dst = site(dst, n);
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+template <typename T>
+static int predict_common(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* mean, T** V_out, T** Xst_out,
+                          T** vpad_out, long* wbs_out, hipStream_t s) {
   const long M = round_up(m, DGP_TILE_HOST);
   const size_t e = sizeof(T);
+  const long wbs = p->B > 1 ? (long)(predict_site_bytes(p, m) / e) : 0;
   char* w = (char*)work;
   T* Xst = (T*)w; w += align_up(e * M * p->d);
   T* Ks = (T*)w; w += align_up(e * (size_t)p->N * M);
@@ -646,12 +672,29 @@ static int predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, 
   T* mpad = (T*)w; w += align_up(e * M);
   T* vpad = (T*)w; w += align_up(e * M);
   T* part = (T*)w;
-  int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s);
+  const unsigned Bz = (unsigned)p->B;
+  int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s, wbs);
   if (rc) return rc;
-  if ((rc = gram_diag<T>(p->model, p->d, Xst, M, (int)m, theta, kss, s))) return rc;
-  if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, part, mpad, vpad, s))) return rc;
-  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean, 0);
-  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(vpad, m, (T*)var, 0);
+  Batch wb;
+  wb.B = p->B;
+  if ((rc = gram_diag<T>(p->model, p->d, Xst, M, (int)m, theta, kss, s, wb, wbs, p->pre))) return rc;
+  if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, part, mpad, vpad, s, batch_of<T>(p), wbs))) return rc;
+  copy_rows_kernel<T><<<dim3((unsigned)((m + 255) / 256), 1, Bz), 256, 0, s>>>(mpad, m, (T*)mean, wbs);
+  *V_out = V;
+  *Xst_out = Xst;
+  *vpad_out = vpad;
+  *wbs_out = wbs;
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* mean, void* var,
+                   hipStream_t s) {
+  T *V, *Xst, *vpad;
+  long wbs;
+  int rc = predict_common<T>(p, theta, Xs, m, work, mean, &V, &Xst, &vpad, &wbs, s);
+  if (rc) return rc;
+  copy_rows_kernel<T><<<dim3((unsigned)((m + 255) / 256), 1, (unsigned)p->B), 256, 0, s>>>(vpad, m, (T*)var, wbs);
   return (int)hipGetLastError();
 }
 
@@ -659,21 +702,11 @@ template <typename T>
 static int post_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, void* mean, void* cov,
                     hipStream_t s) {
   const long M = round_up(m, DGP_TILE_HOST);
-  const size_t e = sizeof(T);
-  char* w = (char*)work;
-  T* Xst = (T*)w; w += align_up(e * M * p->d);
-  T* Ks = (T*)w; w += align_up(e * (size_t)p->N * M);
-  T* V = (T*)w; w += align_up(e * (size_t)p->N * M);
-  T* kss = (T*)w; w += align_up(e * M);
-  T* mpad = (T*)w; w += align_up(e * M);
-  T* vpad = (T*)w; w += align_up(e * M);
-  T* part = (T*)w;
-  int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s);
+  T *V, *Xst, *vpad;
+  long wbs;
+  int rc = predict_common<T>(p, theta, Xs, m, work, mean, &V, &Xst, &vpad, &wbs, s);
   if (rc) return rc;
-  if ((rc = gram_diag<T>(p->model, p->d, Xst, M, (int)m, theta, kss, s))) return rc;
-  if ((rc = predict_var<T>((const T*)p->Tm, p->N, Ks, M, V, (const T*)p->alpha, kss, part, mpad, vpad, s))) return rc;
-  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>(mpad, m, (T*)mean, 0);
-  hipError_t he = hipMemsetAsync(vpad, 0, e * M, s);  // zero "noise" for K(Xs, Xs)
+  hipError_t he = hipMemsetAsync(vpad, 0, sizeof(T) * M, s);  // zero "noise" for K(Xs, Xs)
   if (he != hipSuccess) return (int)he;
   if ((rc = gram_sym<T>(p->model, p->d, Xst, M, (int)m, theta, vpad, (T*)cov, s))) return rc;
   return posterior_cov<T>(V, p->N, M, (T*)cov, s);
@@ -689,7 +722,7 @@ static VjpLayout vjp_layout(const dgp_plan* p, int64_t m) {
   size_t o = 0;
   L.Xst = o; o += align_up(e * M * p->d);
   L.Ks = o; o += align_up(e * N * M);
-  L.g = o; o += align_up(e * N);
+  L.g = o; o += align_up(e * (N > M ? N : M));
   L.beta = o; o += align_up(e * N);
   L.part = o; o += align_up(e * 24 * (blocks_sym > blocks_cross ? blocks_sym : blocks_cross));
   L.spart = o; o += align_up(e * (size_t)solve_partials(p->N));
@@ -698,8 +731,12 @@ static VjpLayout vjp_layout(const dgp_plan* p, int64_t m) {
 }
 
 template <typename T>
-__global__ void matvec_cols_kernel(const T* Ks, long N, long Mp, int n, const T* alpha, T* out) {
+__global__ void matvec_cols_kernel(const T* Ks, long N, long Mp, int n, const T* alpha, T* out, long bs, long wbs, const int* ns) {
   // out[j] = sum_i Ks[i][j] alpha_i : one thread per column, coalesced across columns
+  Ks = site(Ks, wbs);
+  out = site(out, wbs);
+  alpha = site(alpha, bs);
+  n = site_n(ns, n);
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= Mp) return;
   T acc = T(0);
@@ -712,12 +749,14 @@ static int predict_mean(dgp_plan* p, const double* theta, const void* Xs, int64_
                         hipStream_t s) {
   const VjpLayout L = vjp_layout(p, m);
   const long M = round_up(m, DGP_TILE_HOST);
+  const long wbs = p->B > 1 ? (long)(L.total / sizeof(T)) : 0;
+  const Batch bt = batch_of<T>(p);
   char* w = (char*)work;
-  int rc = cross<T>(p, theta, Xs, m, w + L.Xst, w + L.Ks, s);
+  int rc = cross<T>(p, theta, Xs, m, w + L.Xst, w + L.Ks, s, wbs);
   if (rc) return rc;
-  matvec_cols_kernel<T><<<(unsigned)((M + 255) / 256), 256, 0, s>>>((const T*)(w + L.Ks), p->N, M, (int)p->n,
-                                                                  (const T*)p->alpha, (T*)(w + L.g));
-  copy_n_kernel<T><<<(unsigned)((m + 255) / 256), 256, 0, s>>>((const T*)(w + L.g), m, (T*)mean, 0);
+  matvec_cols_kernel<T><<<dim3((unsigned)((M + 255) / 256), 1, (unsigned)p->B), 256, 0, s>>>((const T*)(w + L.Ks), p->N, M, (int)p->n,
+                                                                                           (const T*)p->alpha, (T*)(w + L.g), bt.ws, wbs, bt.ns);
+  copy_rows_kernel<T><<<dim3((unsigned)((m + 255) / 256), 1, (unsigned)p->B), 256, 0, s>>>((const T*)(w + L.g), m, (T*)mean, wbs);
   return (int)hipGetLastError();
 }
 
@@ -726,20 +765,23 @@ static int mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m,
                     void* dtheta, void* dr, void* dnoise, hipStream_t s) {
   const VjpLayout L = vjp_layout(p, m);
   const long M = round_up(m, DGP_TILE_HOST);
+  const long wbs = p->B > 1 ? (long)(L.total / sizeof(T)) : 0;
+  const Batch bt = batch_of<T>(p);
   char* w = (char*)work;
   T* Xst = (T*)(w + L.Xst);
   T* Ks = (T*)(w + L.Ks);
   T* g = (T*)(w + L.g);
   T* beta = (T*)(w + L.beta);
-  int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s);
+  int rc = cross<T>(p, theta, Xs, m, Xst, Ks, s, wbs);
   if (rc) return rc;
-  if ((rc = gemv_rows<T>(Ks, p->N, M, (int)m, (const T*)wts, g, s))) return rc;             // g = K(X, X*) w
+  if ((rc = gemv_rows<T>(Ks, p->N, M, (int)m, (const T*)wts, g, s, p->B, wbs))) return rc;   // g = K(X, X*) w
   if ((rc = symv_lower<T>((const T*)p->S, p->N, g, (int)p->n, (const T*)p->alpha, beta, (T*)(w + L.spart),
-                          (T*)dnoise, s)))                                                   // beta = K^^-1 g
+                          (T*)dnoise, s, bt, wbs)))                                         // beta = K^^-1 g
     return rc;
-  if (dr) copy_n_kernel<T><<<(unsigned)((p->n + 255) / 256), 256, 0, s>>>(beta, p->n, (T*)dr, 0);
+  if (dr) copy_rows_kernel<T><<<dim3((unsigned)((p->n + 255) / 256), 1, (unsigned)p->B), 256, 0, s>>>(beta, p->n, (T*)dr, wbs);
+  PreSlot slot(p, s);
   return mean_vjp_grad<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, Xst, M, (int)m, theta, (const T*)p->alpha,
-                          beta, (const T*)wts, (T*)(w + L.part), (T*)dtheta, s);
+                          beta, (const T*)wts, (T*)(w + L.part), (T*)dtheta, s, bt, wbs, p->B > 1 ? p->ntheta : 0, p->pre, slot.staging);
 }
 
 #define DGP_BY_DTYPE(p, CALL64, CALL32) ((p)->dtype == DGP_F64 ? (CALL64) : (CALL32))
@@ -748,23 +790,7 @@ static int mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m,
   if (!(p)->ws) return fail(DGP_E_WORKSPACE, "plan has no workspace: call dgp_plan_set_workspace")
 #define DGP_SINGLE_SITE(p) \
   if ((p)->B != 1)         \
-  return fail(DGP_E_STATE, "batched plans support dgp_set_inputs / dgp_fit_step / dgp_factorize / dgp_predict / dgp_predict_mean only")
-// Site b of a batched plan as a single-site plan: a shallow copy whose buffers point into that site's slice of the
-// workspace and whose n is the site's own size (ragged batches).  Never destroyed; owns nothing.
-static dgp_plan site_view(const dgp_plan* p, int b) {
-  dgp_plan v = *p;
-  if (p->B == 1) return v;
-  const size_t off = p->site_bytes * (size_t)b;
-  auto shift = [&](void* q) { return (void*)((char*)q + off); };
-  v.Xt = shift(p->Xt); v.A = shift(p->A); v.Tm = shift(p->Tm); v.S = shift(p->S); v.z = shift(p->z);
-  v.alpha = shift(p->alpha); v.gpart = shift(p->gpart); v.spart = shift(p->spart); v.scal = shift(p->scal);
-  v.info = (int*)shift(p->info);
-  v.B = 1;
-  v.n = p->nsite_host ? p->nsite_host[b] : p->n;
-  v.nsite = nullptr;
-  v.pre = nullptr;
-  return v;
-}
+  return fail(DGP_E_STATE, "batched plans support dgp_set_inputs / dgp_fit_step / dgp_factorize / dgp_predict / dgp_predict_mean / dgp_mean_vjp only")
 static int wrap(int rc, const char* where) {
   if (rc > 0) return hipfail((hipError_t)rc, where);
   if (rc < 0) return fail(rc, where);
@@ -807,9 +833,7 @@ int dgp_factorize(dgp_plan* p, const double* theta, const void* r, const void* n
 
 size_t dgp_predict_workspace_bytes(const dgp_plan* p, int64_t m) {
   if (!p || m <= 0) return 0;
-  const size_t M = (size_t)round_up(m, DGP_TILE_HOST), e = p->elem;
-  return align_up(e * M * p->d) + 2 * align_up(e * (size_t)p->N * M) + 3 * align_up(e * M) +
-         align_up(e * 2 * PREDICT_SPLIT * M);
+  return predict_site_bytes(p, m) * (size_t)p->B;
 }
 
 int dgp_predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
@@ -819,14 +843,7 @@ int dgp_predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, voi
   if (!p->have_factor) return fail(DGP_E_STATE, "dgp_predict: no factorisation in the plan (call dgp_factorize)");
   if (work_bytes < dgp_predict_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_predict: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int rc = 0;
-  for (int b = 0; b < p->B && !rc; ++b) {  // the sites share `work`: their launches follow each other on the stream
-    dgp_plan v = site_view(p, b);
-    const size_t xo = (size_t)b * (size_t)m * p->d * p->elem, vo = (size_t)b * (size_t)m * p->elem;
-    const double* th = theta + (size_t)b * p->ntheta;
-    rc = DGP_BY_DTYPE(p, predict<double>(&v, th, (const char*)Xs + xo, m, work, (char*)mean + vo, (char*)var + vo, s),
-                      predict<float>(&v, th, (const char*)Xs + xo, m, work, (char*)mean + vo, (char*)var + vo, s));
-  }
+  const int rc = DGP_BY_DTYPE(p, predict<double>(p, theta, Xs, m, work, mean, var, s), predict<float>(p, theta, Xs, m, work, mean, var, s));
   return wrap(rc, "dgp_predict");
 }
 
@@ -843,7 +860,7 @@ int dgp_posterior_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t 
   return wrap(rc, "dgp_posterior_cov");
 }
 
-size_t dgp_mean_vjp_workspace_bytes(const dgp_plan* p, int64_t m) { return (p && m > 0) ? vjp_layout(p, m).total : 0; }
+size_t dgp_mean_vjp_workspace_bytes(const dgp_plan* p, int64_t m) { return (p && m > 0) ? vjp_layout(p, m).total * (size_t)p->B : 0; }
 
 int dgp_predict_mean(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
                      void* mean, void* stream) {
@@ -852,21 +869,13 @@ int dgp_predict_mean(dgp_plan* p, const double* theta, const void* Xs, int64_t m
   if (!p->have_factor) return fail(DGP_E_STATE, "dgp_predict_mean: no factorisation in the plan");
   if (work_bytes < dgp_mean_vjp_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_predict_mean: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int rc = 0;
-  for (int b = 0; b < p->B && !rc; ++b) {
-    dgp_plan v = site_view(p, b);
-    const size_t xo = (size_t)b * (size_t)m * p->d * p->elem, vo = (size_t)b * (size_t)m * p->elem;
-    const double* th = theta + (size_t)b * p->ntheta;
-    rc = DGP_BY_DTYPE(p, predict_mean<double>(&v, th, (const char*)Xs + xo, m, work, (char*)mean + vo, s),
-                      predict_mean<float>(&v, th, (const char*)Xs + xo, m, work, (char*)mean + vo, s));
-  }
+  const int rc = DGP_BY_DTYPE(p, predict_mean<double>(p, theta, Xs, m, work, mean, s), predict_mean<float>(p, theta, Xs, m, work, mean, s));
   return wrap(rc, "dgp_predict_mean");
 }
 
 int dgp_mean_vjp(dgp_plan* p, const double* theta, const void* Xs, int64_t m, const void* wts, void* work,
                  size_t work_bytes, void* dtheta, void* dr, void* dnoise, void* stream) {
   DGP_CHECK_PLAN(p);
-  DGP_SINGLE_SITE(p);
   if (!theta || !Xs || !wts || !work || !dtheta || m <= 0) return fail(DGP_E_ARG, "dgp_mean_vjp: null argument");
   if (!p->have_factor || !p->have_inverse)
     return fail(DGP_E_STATE, "dgp_mean_vjp: needs K^^-1 and alpha from dgp_fit_step at the same theta");

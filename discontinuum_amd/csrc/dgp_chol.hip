@@ -970,7 +970,10 @@ __global__ __launch_bounds__(256) void trmv_t_reduce_kernel(const T* __restrict_
 // row part  sum_{j <= i} S[i][j] g_j  +  column part  sum_{i > j} S[i][j] g_i
 template <typename T>
 __global__ __launch_bounds__(256) void symv_row_kernel(const T* __restrict__ S, long ld, const T* __restrict__ g,
-                                                       T* __restrict__ out) {
+                                                       T* __restrict__ out, long bs, long wbs) {
+  S = site(S, bs);
+  g = site(g, wbs);
+  out = site(out, wbs);
   const int lane = threadIdx.x & 63;
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const T* row = S + i * ld;
@@ -981,7 +984,10 @@ __global__ __launch_bounds__(256) void symv_row_kernel(const T* __restrict__ S, 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void symv_col_kernel(const T* __restrict__ S, long ld, const T* __restrict__ g,
-                                                       T* __restrict__ partial) {
+                                                       T* __restrict__ partial, long bs, long wbs) {
+  S = site(S, bs);
+  g = site(g, wbs);
+  partial = site(partial, wbs);
   __shared__ T red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long j = (long)blockIdx.x * 64 + tx;
@@ -996,23 +1002,32 @@ __global__ __launch_bounds__(256) void symv_col_kernel(const T* __restrict__ S, 
 template <typename T>
 __global__ __launch_bounds__(256) void symv_finish_kernel(const T* __restrict__ partial, long N, int nchunks,
                                                           const T* __restrict__ alpha, int n, T* __restrict__ beta,
-                                                          T* __restrict__ dnoise) {
+                                                          T* __restrict__ dnoise, long bs, long wbs, const int* __restrict__ ns) {
+  partial = site(partial, wbs);
+  beta = site(beta, wbs);
+  alpha = site(alpha, bs);
+  if (dnoise) dnoise = site(dnoise, (long)n);
+  const int nfull = n;
+  n = site_n(ns, n);
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= N) return;
   T acc = beta[j];  // row part
   for (int c = (int)(j / DGP_TRMV_CHUNK); c < nchunks; ++c) acc += partial[(long)c * N + j];
   acc = j < n ? acc : T(0);
   beta[j] = acc;
-  if (j < n && dnoise) dnoise[j] = -acc * alpha[j];
+  if (j < nfull && dnoise) dnoise[j] = j < n ? -acc * alpha[j] : T(0);
 }
 
 template <typename T>
-int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T* partials, T* dnoise, hipStream_t s) {
+int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T* partials, T* dnoise, hipStream_t s,
+               Batch bt, long wbs) {
   const int nchunks = (int)((N + DGP_TRMV_CHUNK - 1) / DGP_TRMV_CHUNK);
-  symv_row_kernel<T><<<(unsigned)(N / 4), 256, 0, s>>>(S, N, g, beta);
-  dim3 grid((unsigned)(N / 64), (unsigned)nchunks);
-  symv_col_kernel<T><<<grid, 256, 0, s>>>(S, N, g, partials);
-  symv_finish_kernel<T><<<(unsigned)((N + 255) / 256), 256, 0, s>>>(partials, N, nchunks, alpha, n, beta, dnoise);
+  const unsigned Bz = (unsigned)bt.B;
+  symv_row_kernel<T><<<dim3((unsigned)(N / 4), 1, Bz), 256, 0, s>>>(S, N, g, beta, bt.ws, wbs);
+  dim3 grid((unsigned)(N / 64), (unsigned)nchunks, Bz);
+  symv_col_kernel<T><<<grid, 256, 0, s>>>(S, N, g, partials, bt.ws, wbs);
+  symv_finish_kernel<T><<<dim3((unsigned)((N + 255) / 256), 1, Bz), 256, 0, s>>>(partials, N, nchunks, alpha, n, beta, dnoise, bt.ws,
+                                                                                wbs, bt.ns);
   return (int)hipGetLastError();
 }
 
@@ -1053,7 +1068,10 @@ int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s, 
 // mean_j = sum_i Ks_ij alpha_i      (src/discontinuum/engines/gpytorch.py:621-624)
 template <typename T>
 __global__ __launch_bounds__(256, 2) void predict_v_kernel(const T* __restrict__ Tm, long N, const T* __restrict__ Ks,
-                                                        long M, T* __restrict__ V) {
+                                                        long M, T* __restrict__ V, long bs, long wbs) {
+  Tm = site(Tm, bs);  // batched plans: blockIdx.z = site; Ks, V in the caller's work area (site stride wbs)
+  Ks = site(Ks, wbs);
+  V = site(V, wbs);
   using G = TileGemm<T, true, false>;
   __shared__ T smem[G::SMEM_ELEMS];
   const int bi = gridDim.y - 1 - blockIdx.y, bj = blockIdx.x;  // longest row blocks first
@@ -1068,7 +1086,12 @@ __global__ __launch_bounds__(256, 2) void predict_v_kernel(const T* __restrict__
 // 64 columns x 4 row lanes per workgroup; (M/64) x PREDICT_SPLIT workgroups keep every CU reading.
 template <typename T>
 __global__ __launch_bounds__(256) void predict_partial_kernel(const T* __restrict__ V, const T* __restrict__ Ks, long N,
-                                                              long M, const T* __restrict__ alpha, T* __restrict__ part) {
+                                                              long M, const T* __restrict__ alpha, T* __restrict__ part, long bs,
+                                                              long wbs) {
+  V = site(V, wbs);
+  Ks = site(Ks, wbs);
+  part = site(part, wbs);
+  alpha = site(alpha, bs);
   __shared__ T r1[4][64], r2[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long j = (long)blockIdx.x * 64 + tx;
@@ -1091,7 +1114,11 @@ __global__ __launch_bounds__(256) void predict_partial_kernel(const T* __restric
 
 template <typename T>
 __global__ __launch_bounds__(256) void predict_finish_kernel(const T* __restrict__ part, long M, const T* __restrict__ kss,
-                                                             T* __restrict__ mean, T* __restrict__ var) {
+                                                             T* __restrict__ mean, T* __restrict__ var, long wbs) {
+  part = site(part, wbs);
+  kss = site(kss, wbs);
+  mean = site(mean, wbs);
+  var = site(var, wbs);
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= M) return;
   T s1 = T(0), s2 = T(0);
@@ -1105,11 +1132,12 @@ __global__ __launch_bounds__(256) void predict_finish_kernel(const T* __restrict
 
 template <typename T>
 int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* part, T* mean, T* var,
-                hipStream_t s) {
-  dim3 grid((unsigned)(M / NB), (unsigned)(N / NB));
-  predict_v_kernel<T><<<grid, 256, 0, s>>>(Tm, N, Ks, M, V);
-  predict_partial_kernel<T><<<dim3((unsigned)(M / 64), PREDICT_SPLIT), 256, 0, s>>>(V, Ks, N, M, alpha, part);
-  predict_finish_kernel<T><<<(unsigned)((M + 255) / 256), 256, 0, s>>>(part, M, kss, mean, var);
+                hipStream_t s, Batch bt, long wbs) {
+  const unsigned Bz = (unsigned)bt.B;
+  dim3 grid((unsigned)(M / NB), (unsigned)(N / NB), Bz);
+  predict_v_kernel<T><<<grid, 256, 0, s>>>(Tm, N, Ks, M, V, bt.ws, wbs);
+  predict_partial_kernel<T><<<dim3((unsigned)(M / 64), PREDICT_SPLIT, Bz), 256, 0, s>>>(V, Ks, N, M, alpha, part, bt.ws, wbs);
+  predict_finish_kernel<T><<<dim3((unsigned)((M + 255) / 256), 1, Bz), 256, 0, s>>>(part, M, kss, mean, var, wbs);
   return (int)hipGetLastError();
 }
 
@@ -1167,7 +1195,7 @@ int sample_draws(const T* L, long M, const T* Z, long Q, const T* mean, int m, i
 #define DGP_INST(T)                                                                                              \
   template int posterior_cov<T>(const T*, long, long, T*, hipStream_t);                                          \
   template int sample_draws<T>(const T*, long, const T*, long, const T*, int, int, T*, hipStream_t);             \
-  template int symv_lower<T>(const T*, long, const T*, int, const T*, T*, T*, T*, hipStream_t);                  \
+  template int symv_lower<T>(const T*, long, const T*, int, const T*, T*, T*, T*, hipStream_t, Batch, long);     \
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \
                         const int*, hipEvent_t*, void (*)(void*, int), void*, Batch, int, PotrfCarry*);                                                                                        \
   template int potrf_split<T>(T*, long, T*, T*, int*, T*, hipStream_t, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, \
@@ -1178,7 +1206,7 @@ int sample_draws(const T* L, long M, const T* Z, long Q, const T* mean, int m, i
   template int lauum<T>(const T*, long, T*, hipStream_t, Batch);                                                      \
   template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t, Batch);                           \
   template int finish<T>(const T*, const T*, long, int, T*, hipStream_t, Batch);                                      \
-  template int predict_var<T>(const T*, long, const T*, long, T*, const T*, const T*, T*, T*, T*, hipStream_t);
+  template int predict_var<T>(const T*, long, const T*, long, T*, const T*, const T*, T*, T*, T*, hipStream_t, Batch, long);
 DGP_INST(double)
 DGP_INST(float)
 

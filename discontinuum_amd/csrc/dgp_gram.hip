@@ -184,10 +184,17 @@ __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt,
   }
 }
 
+// Batched plans (blockIdx.z = site): the training coordinates sit at the plan's site stride `bs`, the test coordinates
+// and the output in the caller's work area at its own site stride `wbs`; ragged sites have n = ns[site] rows.
 template <typename T, typename M>
 __global__ __launch_bounds__(256) void gram_cross_kernel(const T* __restrict__ Xt, long N, int n,
-                                                         const T* __restrict__ Xst, long Mp, int m, const typename M::Pre pre,
-                                                         T* __restrict__ Ks) {
+                                                         const T* __restrict__ Xst, long Mp, int m, const PreBatch<M> pb,
+                                                         T* __restrict__ Ks, long bs, long wbs, const int* __restrict__ ns) {
+  const typename M::Pre& pre = pb.get();
+  Xt = site(Xt, bs);
+  Xst = site(Xst, wbs);
+  Ks = site(Ks, wbs);
+  n = site_n(ns, n);
   __shared__ T sfi[M::NF][64], sfj[M::NF][64];
   const int bi = blockIdx.y, bj = blockIdx.x;
   const int t = threadIdx.x;
@@ -222,8 +229,11 @@ __global__ __launch_bounds__(256) void gram_cross_kernel(const T* __restrict__ X
 
 // prior variance k(x*, x*) of the test points (diagonal of K**)
 template <typename T, typename M>
-__global__ __launch_bounds__(256) void gram_diag_kernel(const T* __restrict__ Xst, long Mp, int m, const typename M::Pre pre,
-                                                        T* __restrict__ kss) {
+__global__ __launch_bounds__(256) void gram_diag_kernel(const T* __restrict__ Xst, long Mp, int m, const PreBatch<M> pb,
+                                                        T* __restrict__ kss, long wbs) {
+  const typename M::Pre& pre = pb.get();
+  Xst = site(Xst, wbs);
+  kss = site(kss, wbs);
   exp_table_init<T>();
   __syncthreads();
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
@@ -243,13 +253,14 @@ template <typename T, typename M, int MODE>
 __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt, long N, int n, const PreBatch<M> pb,
                                                         const T* __restrict__ S, const T* __restrict__ alpha,
                                                         const T* __restrict__ beta, T* __restrict__ partials, long bs,
-                                                        const int* __restrict__ ns) {
+                                                        const int* __restrict__ ns, long wbs /* MODE 1: stride of beta / partials */) {
   n = site_n(ns, n);
   const typename M::Pre& pre = pb.get();
   Xt = site(Xt, bs);
   if (MODE == 0) S = site(S, bs);
   alpha = site(alpha, bs);
-  partials = site(partials, bs);
+  partials = site(partials, MODE == 0 ? bs : wbs);
+  if (MODE == 1) beta = site(beta, wbs);
   __shared__ T sfi[M::NF][64], sfj[M::NF][64], sai[64], saj[64], sbi[64], sbj[64];
   __shared__ T red[4][M::NTHETA];
   int bi, bj;
@@ -312,8 +323,16 @@ __global__ __launch_bounds__(256) void gram_grad_kernel(const T* __restrict__ Xt
 template <typename T, typename M>
 __global__ __launch_bounds__(256) void gram_cross_grad_kernel(const T* __restrict__ Xt, long N, int n,
                                                               const T* __restrict__ Xst, long Mp, int m,
-                                                              const typename M::Pre pre, const T* __restrict__ alpha,
-                                                              const T* __restrict__ wts, T* __restrict__ partials) {
+                                                              const PreBatch<M> pb, const T* __restrict__ alpha,
+                                                              const T* __restrict__ wts, T* __restrict__ partials, long bs,
+                                                              long wbs, const int* __restrict__ ns) {
+  const typename M::Pre& pre = pb.get();
+  Xt = site(Xt, bs);
+  alpha = site(alpha, bs);
+  Xst = site(Xst, wbs);
+  partials = site(partials, wbs);
+  wts = site(wts, (long)m);
+  n = site_n(ns, n);
   __shared__ T sfi[M::NF][64], sfj[M::NF][64], sai[64], swj[64];
   __shared__ T red[4][M::NTHETA];
   const int bi = blockIdx.y, bj = blockIdx.x;
@@ -362,7 +381,10 @@ __global__ __launch_bounds__(256) void gram_cross_grad_kernel(const T* __restric
 // g_i = sum_j Ks[i][j] w_j  (N x Mp row-major, one wave per row)
 template <typename T>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const T* __restrict__ Ks, long N, long Mp, int m,
-                                                        const T* __restrict__ w, T* __restrict__ out) {
+                                                        const T* __restrict__ w, T* __restrict__ out, long wbs) {
+  Ks = site(Ks, wbs);
+  out = site(out, wbs);
+  w = site(w, (long)m);
   const int lane = threadIdx.x & 63;
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= N) return;
@@ -552,20 +574,25 @@ int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, 
 
 template <typename T>
 int gram_cross(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,
-               T* Ks, hipStream_t s) {
+               T* Ks, hipStream_t s, Batch bt, long wbs, void* pre_scratch, void* pre_staging) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
-  dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64));
-  DGP_DISPATCH_MODEL(model, d, (gram_cross_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xt, N, n, Xst, Mp, m, M::prepare(theta), Ks)));
+  dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64), (unsigned)bt.B);
+  DGP_DISPATCH_MODEL(model, d, (gram_cross_kernel<T, M><<<grid, dim3(256), 0, s>>>(
+                                   Xt, N, n, Xst, Mp, m, prepare_batch<M>(theta, nt, bt.B, pre_scratch, true, s, pre_staging), Ks, bt.ws,
+                                   wbs, bt.ns)));
   return (int)hipGetLastError();
 }
 
+// pre_ready: the hyperparameters of a batch of more than 8 are already in pre_scratch (gram_cross of the same call)
 template <typename T>
-int gram_diag(int model, int d, const T* Xst, long Mp, int m, const double* theta, T* kss, hipStream_t s) {
+int gram_diag(int model, int d, const T* Xst, long Mp, int m, const double* theta, T* kss, hipStream_t s, Batch bt, long wbs,
+              void* pre_scratch) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
-  dim3 grid((unsigned)((Mp + 255) / 256));
-  DGP_DISPATCH_MODEL(model, d, (gram_diag_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xst, Mp, m, M::prepare(theta), kss)));
+  dim3 grid((unsigned)((Mp + 255) / 256), 1, (unsigned)bt.B);
+  DGP_DISPATCH_MODEL(model, d, (gram_diag_kernel<T, M><<<grid, dim3(256), 0, s>>>(
+                                   Xst, Mp, m, prepare_batch<M>(theta, nt, bt.B, pre_scratch, false, s), kss, wbs)));
   return (int)hipGetLastError();
 }
 
@@ -585,29 +612,34 @@ int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta,
   DGP_DISPATCH_MODEL(model, d,
                      (gram_grad_kernel<T, M, 0><<<dim3((unsigned)nblk, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
                          Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, !pre_ready, s, pre_staging), S, alpha, nullptr,
-                         partials, bt.ws, bt.ns)));
+                         partials, bt.ws, bt.ns, 0)));
   grad_reduce_kernel<T><<<dim3((unsigned)nt, 1, (unsigned)bt.B), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, bt.ws,
                                                                                  dtheta_stride);
   return (int)hipGetLastError();
 }
 
-// dtheta = -b^T dK a (symmetric part) + sum_ij a_i w_j dK*_ij   -- the two kernel-gradient terms of the mean VJP
+// dtheta = -b^T dK a (symmetric part) + sum_ij a_i w_j dK*_ij   -- the two kernel-gradient terms of the mean VJP.
+// Batched: beta, partials and Xst live in the caller's work area (site stride wbs), wts is [B][m], dtheta [B][dstride].
 template <typename T>
 int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,
-                  const T* alpha, const T* beta, const T* wts, T* partials, T* dtheta, hipStream_t s) {
+                  const T* alpha, const T* beta, const T* wts, T* partials, T* dtheta, hipStream_t s, Batch bt, long wbs,
+                  long dstride, void* pre_scratch, void* pre_staging) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
   const long nb = N / 64;
   const long nblk = nb * (nb + 1) / 2;
+  const unsigned Bz = (unsigned)bt.B;
   DGP_DISPATCH_MODEL(model, d,
-                     (gram_grad_kernel<T, M, 1><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(
-                         Xt, N, n, prepare_batch<M>(theta, nt, 1, nullptr, false, s), nullptr, alpha, beta, partials, 0, nullptr)));
-  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, 0, 0);
-  dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64));
+                     (gram_grad_kernel<T, M, 1><<<dim3((unsigned)nblk, 1, Bz), dim3(256), 0, s>>>(
+                         Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, true, s, pre_staging), nullptr, alpha, beta, partials,
+                         bt.ws, bt.ns, wbs)));
+  grad_reduce_kernel<T><<<dim3((unsigned)nt, 1, Bz), dim3(256), 0, s>>>(partials, nblk, nt, dtheta, 0, wbs, dstride);
+  dim3 grid((unsigned)(Mp / 64), (unsigned)(N / 64), Bz);
   DGP_DISPATCH_MODEL(model, d,
-                     (gram_cross_grad_kernel<T, M><<<grid, dim3(256), 0, s>>>(Xt, N, n, Xst, Mp, m, M::prepare(theta), alpha, wts,
-                                                                             partials)));
-  grad_reduce_kernel<T><<<dim3((unsigned)nt), dim3(256), 0, s>>>(partials, (long)grid.x * grid.y, nt, dtheta, 1, 0, 0);
+                     (gram_cross_grad_kernel<T, M><<<grid, dim3(256), 0, s>>>(
+                         Xt, N, n, Xst, Mp, m, prepare_batch<M>(theta, nt, bt.B, pre_scratch, false, s), alpha, wts, partials, bt.ws, wbs,
+                         bt.ns)));
+  grad_reduce_kernel<T><<<dim3((unsigned)nt, 1, Bz), dim3(256), 0, s>>>(partials, (long)grid.x * grid.y, nt, dtheta, 1, wbs, dstride);
   return (int)hipGetLastError();
 }
 
@@ -635,21 +667,21 @@ int gram_grad_slab(int model, int d, const T* Xt, long N, int n, const double* t
 }
 
 template <typename T>
-int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream_t s) {
-  gemv_rows_kernel<T><<<(unsigned)((N + 3) / 4), 256, 0, s>>>(Ks, N, Mp, m, w, out);
+int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream_t s, int B, long wbs) {
+  gemv_rows_kernel<T><<<dim3((unsigned)((N + 3) / 4), 1, (unsigned)B), 256, 0, s>>>(Ks, N, Mp, m, w, out, wbs);
   return (int)hipGetLastError();
 }
 
 #define DGP_INST(T)                                                                                              \
   template int pack_x<T>(const T*, int, int, long, T*, hipStream_t, Batch);                                      \
   template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t, Batch, void*, void*); \
-  template int gram_cross<T>(int, int, const T*, long, int, const T*, long, int, const double*, T*, hipStream_t); \
-  template int gram_diag<T>(int, int, const T*, long, int, const double*, T*, hipStream_t);                      \
+  template int gram_cross<T>(int, int, const T*, long, int, const T*, long, int, const double*, T*, hipStream_t, Batch, long, void*, void*); \
+  template int gram_diag<T>(int, int, const T*, long, int, const double*, T*, hipStream_t, Batch, long, void*);    \
   template int gram_grad<T>(int, int, const T*, long, int, const double*, const T*, const T*, T*, T*, hipStream_t, Batch, \
                             long, void*, bool, void*);                                                         \
   template int mean_vjp_grad<T>(int, int, const T*, long, int, const T*, long, int, const double*, const T*, const T*, \
-                                const T*, T*, T*, hipStream_t);                                                    \
-  template int gemv_rows<T>(const T*, long, long, int, const T*, T*, hipStream_t);                              \
+                                const T*, T*, T*, hipStream_t, Batch, long, long, void*, void*);                    \
+  template int gemv_rows<T>(const T*, long, long, int, const T*, T*, hipStream_t, int, long);                   \
   template int gram_slab<T>(int, int, const T*, long, int, const double*, const T*, T*, long, SlabMap, hipStream_t); \
   template int gram_grad_slab<T>(int, int, const T*, long, int, const double*, const T*, long, SlabMap, const T*, T*, T*, T*, \
                                  hipStream_t);

@@ -29,11 +29,14 @@ template <typename T>
 int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s,
              Batch bt = Batch(), void* pre_scratch = nullptr /* pre_scratch_bytes(B) of device memory, B > 8 */,
              void* pre_staging = nullptr /* pinned host memory of the same size that outlives the copy, or null: blocking copy */);
+// The inference launchers take a Batch like the fit-step ones (gridDim.z = sites): training-side arrays at the plan's
+// site stride bt.ws, everything in the caller's work area (test coordinates, cross Gram, partials ...) at `wbs` elements.
 template <typename T>
 int gram_cross(int model, int d, const T* Xt, long N, int n, const T* Xst, long M, int m, const double* theta,
-               T* Ks, hipStream_t s);
+               T* Ks, hipStream_t s, Batch bt = Batch(), long wbs = 0, void* pre_scratch = nullptr, void* pre_staging = nullptr);
 template <typename T>
-int gram_diag(int model, int d, const T* Xst, long M, int m, const double* theta, T* kss, hipStream_t s);
+int gram_diag(int model, int d, const T* Xst, long M, int m, const double* theta, T* kss, hipStream_t s, Batch bt = Batch(),
+              long wbs = 0, void* pre_scratch = nullptr);
 template <typename T>
 int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta, const T* S, const T* alpha,
               T* partials, T* dtheta, hipStream_t s, Batch bt = Batch(), long dtheta_stride = 0,
@@ -43,9 +46,10 @@ size_t pre_scratch_bytes(int B);  // device scratch for the hyperparameters of a
 long gram_grad_partials(long N);
 template <typename T>
 int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,
-                  const T* alpha, const T* beta, const T* wts, T* partials, T* dtheta, hipStream_t s);
+                  const T* alpha, const T* beta, const T* wts, T* partials, T* dtheta, hipStream_t s, Batch bt = Batch(),
+                  long wbs = 0, long dstride = 0, void* pre_scratch = nullptr, void* pre_staging = nullptr);
 template <typename T>
-int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream_t s);  // number of T elements `partials` must hold
+int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream_t s, int B = 1, long wbs = 0);
 
 // ---- dgp_chol.hip ---------------------------------------------------------------------------
 struct PotrfCarry {  // state of a factorisation that one schedule hands to the next (potrf with q_stop -> potrf_split)
@@ -96,7 +100,7 @@ int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s, 
 #define PREDICT_SPLIT 32
 template <typename T>
 int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, const T* kss, T* part, T* mean, T* var,
-                hipStream_t s);
+                hipStream_t s, Batch bt = Batch(), long wbs = 0);
 long solve_partials(long N);
 // ---- one matrix over several GPUs (dgp_dist.hip): the panel chain of W block columns on a slab-addressed matrix
 template <typename T>
@@ -117,7 +121,8 @@ int gram_grad_slab(int model, int d, const T* Xt, long N, int n, const double* t
                    const T* alpha, T* partials, T* dtheta, T* dnoise_part, hipStream_t s);
 long gram_grad_slab_partials(long N, long Cl);
 template <typename T>
-int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T* partials, T* dnoise, hipStream_t s);
+int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T* partials, T* dnoise, hipStream_t s,
+               Batch bt = Batch(), long wbs = 0);
 // cov (M x M) = Kss - V^T V, lower tiles; Kss already holds K(Xs, Xs) (identity pad)
 template <typename T>
 int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s);

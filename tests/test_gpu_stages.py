@@ -247,6 +247,45 @@ def test_predictive_mean_and_vjp_fp64(model, d, n, m, gpu_device):
     assert (dnoise.cpu() - g_noise).abs().max() / g_noise.abs().max() < 1e-7
 
 
+@pytest.mark.parametrize("model,d,sizes,m", [("rating", 2, [300, 170, 300], 40), ("loadest", 3, [200, 129, 64, 200], 130),
+                                             ("rating", 2, [150] * 12, 70)])  # 12 sites: hyperparameters through the device scratch
+def test_batched_inference_is_one_launch_sequence_and_matches_the_oracle(model, d, sizes, m, gpu_device):
+    """dgp_predict / dgp_predict_mean / dgp_mean_vjp on a (ragged) batched plan -- gridDim.z = sites, no host loop over
+    the sites -- against the oracle's posterior and autograd through its mean, site by site.  Tolerances as for single
+    plans: mean 1e-9, variance 1e-8, VJP gradients rel 1e-7; rows beyond a site's own size come back as zeros."""
+    from discontinuum_amd.backend import GPPlan
+
+    dev, B, n = gpu_device, len(sizes), max(sizes)
+    cases = [make_case(model, d, nb, seed=30 + b, perturb=0.2) for b, nb in enumerate(sizes)]
+    X = torch.full((B, n, d), float("nan"), dtype=torch.float64)
+    r = torch.full((B, n), float("nan"), dtype=torch.float64)
+    noise = torch.full((B, n), float("nan"), dtype=torch.float64)
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        X[b, :nb], r[b, :nb], noise[b, :nb] = c[0], c[1], c[2]
+    theta = torch.stack([c[3] for c in cases])
+    Xs = torch.stack([make_case(model, d, m, seed=50 + b)[0] for b in range(B)])
+    w = torch.randn(B, m, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    pb = GPPlan(model, n, d, device=dev, lookahead=1, batch=B)
+    pb.set_site_sizes(sizes)
+    pb.set_inputs(X.to(dev).contiguous())
+    pb.fit_step(theta, r.to(dev).contiguous(), noise.to(dev).contiguous())
+    mean, var = pb.predict(theta, Xs.to(dev))
+    mu = pb.predict_mean(theta, Xs.to(dev))
+    dtheta, dr, dnoise = pb.mean_vjp(theta, Xs.to(dev), w.to(dev).contiguous())
+    assert mean.shape == (B, m) and dtheta.shape == (B, pb.ntheta) and dr.shape == (B, n)
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        th, rr, nn = (t.clone().requires_grad_(True) for t in (c[3], c[1], c[2]))
+        mu_ref, var_ref = orc.posterior(model, c[0], rr, nn, th, Xs[b])
+        g_theta, g_r, g_noise = torch.autograd.grad((mu_ref * w[b]).sum(), (th, rr, nn))
+        assert (mean[b].cpu() - mu_ref.detach()).abs().max() < 1e-9
+        assert (mu[b].cpu() - mu_ref.detach()).abs().max() < 1e-9
+        assert (var[b].cpu() - var_ref.detach()).abs().max() <= 1e-8 * max(1.0, var_ref.abs().max().item())
+        assert (dtheta[b].cpu() - g_theta).abs().max() / g_theta.abs().max() < 1e-7
+        assert (dr[b, :nb].cpu() - g_r).abs().max() / g_r.abs().max() < 1e-7
+        assert (dnoise[b, :nb].cpu() - g_noise).abs().max() / g_noise.abs().max() < 1e-7
+        assert bool((dr[b, nb:] == 0).all()) and bool((dnoise[b, nb:] == 0).all())
+
+
 @pytest.mark.parametrize("n", [384, 512, 640, 768, 896, 1024, 1152, 1300])
 def test_lookahead_schedule_matches_plain_schedule(n, gpu_device):
     """Every block-column count (odd / even, with and without a final unpaired panel) through the paired
