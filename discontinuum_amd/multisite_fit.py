@@ -18,7 +18,10 @@ so each site follows the trajectory ``model.fit`` would give it (tests/test_gpu_
 every model holds its fitted parameters and is ready for ``predict``.  Both model families are covered: loadest-gp
 (constant mean, fixed noise) and rating-gp (power-law mean whose parameters the reference clamps in place on every
 forward -- done here once per iteration on the stacked parameters -- and a learned homoskedastic noise term).
-Not supported here: early stopping, resume, penalty callbacks, AdamW.
+Early stopping is per site; the rating-gp monotonicity penalty (``monotonic_penalty_weight``) differentiates every
+site's posterior mean at its own random grid through ONE batched ``dgp_predict_mean`` / ``dgp_mean_vjp`` per iteration;
+``return_state=True`` / ``resume=state`` continue a run where it stopped (optimiser moments, schedules, counters).
+Not supported here: AdamW, arbitrary penalty callbacks.
 """
 from __future__ import annotations
 
@@ -91,6 +94,60 @@ class _BatchedNLL(torch.autograd.Function):
         return None, (dtheta * g).to(ctx.dtypes[0]), None, None, (dextras * g).to(ctx.dtypes[1]), None
 
 
+class _BatchedGPMean(torch.autograd.Function):
+    """K(x*_b, X_b) alpha_b of every site b at its own points (B, m, d) from the factorisation the batched plan holds
+    (the fit step of the same iteration), differentiable: backward runs ONE batched ``dgp_mean_vjp`` and turns its
+    dr / dnoise vectors into the gradients of the mean / noise parameters (``extras``) like ``_BatchedNLL`` does with the
+    result row's reductions.  Used by the monotonicity penalty (src/rating_gp/models/gpytorch.py:130-187)."""
+
+    @staticmethod
+    def forward(ctx, plan, theta, xgrid, extras, family, dr_weights, valid):
+        one = plan.batch == 1
+        th = theta.detach()
+        mu = plan.predict_mean(th[0] if one else th, xgrid[0].contiguous() if one else xgrid)
+        ctx.plan, ctx.family, ctx.one = plan, family, one
+        ctx.save_for_backward(th, xgrid, extras.detach(), dr_weights if dr_weights is not None else torch.empty(0), valid)
+        ctx.dtypes = (theta.dtype, extras.dtype)
+        return mu.reshape(xgrid.shape[0], -1).to("cpu", torch.float64)
+
+    @staticmethod
+    def backward(ctx, g):
+        th, xgrid, extras, dr_w, valid = ctx.saved_tensors
+        plan, one = ctx.plan, ctx.one
+        w = torch.nan_to_num(g, nan=0.0).to(xgrid.device, xgrid.dtype).contiguous()
+        dtheta, dr, dnoise = plan.mean_vjp(th[0] if one else th, xgrid[0].contiguous() if one else xgrid, w[0].contiguous() if one else w)
+        B = xgrid.shape[0]
+        dtheta, dr, dnoise = dtheta.reshape(B, -1), dr.reshape(B, -1) * valid, dnoise.reshape(B, -1) * valid
+        sum_dr = dr.sum(dim=1)
+        if ctx.family == "rating":  # r = y - a - b log(s - c); Sigma = fixed + second_noise
+            w3 = dr_w.reshape(B, 2, -1)
+            dextras = torch.stack([-sum_dr, -(dr * w3[:, 0]).sum(dim=1), extras[:, 1].to(dr) * (dr * w3[:, 1]).sum(dim=1),
+                                   dnoise.sum(dim=1)], dim=1)
+        else:
+            dextras = -sum_dr[:, None]
+        return (None, dtheta.to("cpu", ctx.dtypes[0]), None, dextras.to("cpu", ctx.dtypes[1]), None, None, None)
+
+
+class FitManyState:
+    """Everything ``fit_many`` needs to continue a run: stacked raw parameters, Adam moments and step counts, the
+    per-site learning rates and plateau / early-stopping counters (plain tensors: ``torch.save`` / ``torch.load`` with
+    ``weights_only=True`` round-trips ``state.as_dict()``)."""
+
+    FIELDS = ("params", "m1", "m2", "step", "lr", "best", "num_bad", "cooldown", "es_best", "stale", "live", "last_obj",
+              "last_iteration", "iterations_done")
+
+    def __init__(self, **kw):
+        for k in self.FIELDS:
+            setattr(self, k, kw[k])
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in self.FIELDS}
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(**{k: d[k] for k in cls.FIELDS})
+
+
 def _per_site_clip(raw_grads: dict, B: int, max_norm: float = 1.0):
     """``clip_grad_norm_(max_norm)`` followed by the reference's NaN scan (engines/gpytorch.py:387-400), per site, on
     stacked gradients (leading dimension B).  The norm is taken of the RAW gradient, like the reference and
@@ -106,10 +163,19 @@ def _per_site_clip(raw_grads: dict, B: int, max_norm: float = 1.0):
 
 
 def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.05, patience: int = 60,
-             scheduler: bool = True, progress: bool = False, early_stopping: bool = False):
+             scheduler: bool = True, progress: bool = False, early_stopping: bool = False,
+             monotonic_penalty_weight: float = 0.0, grid_size: int = 64, monotonic_penalty_interval: int = 1,
+             resume: FitManyState | None = None, return_state: bool = False, generator: torch.Generator | None = None,
+             _penalty_uniforms=None):
     """Fit ``models[i]`` to ``datasets[i] = (covariates, target[, target_unc])`` for all i at once.  Returns the
-    per-site final objectives (a float64 tensor); the models are updated in place (``is_fitted``, parameters, device
-    state)."""
+    per-site final objectives (a float64 tensor) -- with ``return_state=True`` the pair (objectives, ``FitManyState``);
+    the models are updated in place (``is_fitted``, parameters, device state).
+
+    ``monotonic_penalty_weight`` > 0 (rating-gp only) adds ``weight * mean(relu(-d mu / d stage))`` of each site's
+    posterior mean on a fresh random grid of ``grid_size`` points per iteration (every ``monotonic_penalty_interval``-th
+    iteration, weighted by the interval), exactly the term of ``RatingGP.fit`` (src/rating_gp/models/gpytorch.py:130-187),
+    for all sites through one batched launch sequence.  ``resume``: the state a previous call returned (same sites, same
+    order) -- ``iterations`` more iterations from there; ``generator`` seeds the penalty grids."""
     if len(models) != len(datasets) or not models:
         raise ValueError("fit_many needs one (covariates, target) pair per model")
     B = len(models)
@@ -155,6 +221,25 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
         stage = torch.where(valid, X[:, :, 1], torch.full_like(X[:, :, 1], 2.0))  # finite filler in the unused slots
         stage_floor = torch.stack([x[:, 1].min() for x in xs]).to(torch.float64) - 1e-6
 
+    use_penalty = monotonic_penalty_weight > 0.0
+    if use_penalty and family != "rating":
+        raise NotImplementedError("the monotonicity penalty is rating-gp's (stage is its second column)")
+    if use_penalty:
+        lo = torch.stack([x.min(dim=0).values for x in xs]).to(torch.float64)  # (B, 2) model-space ranges of every site
+        hi = torch.stack([x.max(dim=0).values for x in xs]).to(torch.float64)
+        FD, interval = 1e-3, max(1, int(monotonic_penalty_interval))
+
+        def penalty_grid():
+            """(B, 2 m, 2): m random points per site -- time uniform over the record, stage log-uniform -- followed by
+            the same points with the stage moved up by the forward-difference step (rating_gp/models.py::_MonotonicPenalty)."""
+            u = (_penalty_uniforms(grid_size).to(torch.float64) if _penalty_uniforms is not None  # test hook: (B, 2, m)
+                 else torch.rand((B, 2, grid_size), dtype=torch.float64, generator=generator))
+            t = lo[:, 0:1] + u[:, 0] * (hi[:, 0:1] - lo[:, 0:1])
+            llo, lhi = torch.log(lo[:, 1:2] + 1e-6), torch.log(hi[:, 1:2] + 1e-6)
+            st = torch.exp(llo + u[:, 1] * (lhi - llo))
+            here, there = torch.stack([t, st], dim=2), torch.stack([t, st + FD], dim=2)
+            return torch.cat([here, there], dim=1)
+
     def mean_and_noise(extras):
         """Prior mean and noise diagonal of every site in its slots, built on the device WITHOUT autograd from the
         current values of ``extras``; for rating-gp also the two weight vectors whose reductions give the power
@@ -165,8 +250,10 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
             log_s = torch.log(shifted)
             weights = torch.stack([log_s, torch.reciprocal(shifted)], dim=1).contiguous()  # (B, 2, n)
             plan.set_dr_weights(weights if B > 1 else weights[0].contiguous())
+            mean_and_noise.weights = weights
             return e[:, 0:1] + e[:, 1:2] * log_s, fixed_noise + e[:, 3:4]
         return e[:, 0:1].expand(B, n), fixed_noise
+    mean_and_noise.weights = None
     plan.set_inputs(X if B > 1 else X[0].contiguous())
 
     # stacked state of the per-site host modules: every parameter, and the buffers that have one shape across the
@@ -200,17 +287,30 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     sched_patience, factor, threshold, cool, min_lr = max(20, patience // 2), 0.7, 1e-4, 10, 1e-6
     nan_run = torch.zeros(B, dtype=torch.float64)
     last_obj = torch.full((B,), float("nan"), dtype=torch.float64)
+    it0 = 0
     # early stopping per site (engines/gpytorch.py:407-428): a site that has not improved its best objective by 1e-6
     # for `patience` of its own steps is frozen -- it keeps its slot in the batched step but is no longer updated
     live = torch.ones(B, dtype=torch.bool)
     es_best = torch.full((B,), float("inf"), dtype=torch.float64)
     stale = torch.zeros(B, dtype=torch.float64)
     last_iteration = torch.full((B,), iterations - 1, dtype=torch.int64)
+    if resume is not None:
+        if set(resume.params) != set(params) or any(resume.params[k].shape != params[k].shape for k in params):
+            raise ValueError("resume: the state belongs to a different set of sites / models")
+        with torch.no_grad():
+            for k in params:
+                params[k].copy_(resume.params[k])
+        m1 = {k: v.clone() for k, v in resume.m1.items()}
+        m2 = {k: v.clone() for k, v in resume.m2.items()}
+        step, lr, best, num_bad, cooldown = (getattr(resume, k).clone() for k in ("step", "lr", "best", "num_bad", "cooldown"))
+        es_best, stale, live, last_obj = (getattr(resume, k).clone() for k in ("es_best", "stale", "live", "last_obj"))
+        it0 = int(resume.iterations_done)
+        last_iteration = torch.where(live, torch.full_like(resume.last_iteration, it0 + iterations - 1), resume.last_iteration)
 
     def per_site(t, v):  # broadcast a (B,) vector against a stacked parameter
         return v.reshape((B,) + (1,) * (t.dim() - 1))
 
-    for it in range(iterations):
+    for it in range(it0, it0 + iterations):
         for v in params.values():
             v.grad = None
         if family == "rating":  # the reference's in-forward clamps (rating_gp/models/gpytorch.py:39, 259)
@@ -224,6 +324,16 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
         noise = noise.contiguous()
         nll = _BatchedNLL.apply(plan, theta, r, noise, extras, family)
         obj = (nll - lp) / nvec
+        if use_penalty and (it + 1) % interval == 0:
+            # posterior mean of every site on its grid = GP part (device, batched, differentiable through
+            # dgp_mean_vjp) + power-law prior mean at the grid's stages (host autograd)
+            grid = penalty_grid()
+            gp_part = _BatchedGPMean.apply(plan, theta, grid.to(device, dtype).contiguous(), extras, family,
+                                           mean_and_noise.weights, valid.to(dtype))
+            prior = extras[:, 0:1] + extras[:, 1:2] * torch.log(grid[:, :, 1] - extras[:, 2:3])
+            mu = gp_part + prior
+            slope = (mu[:, grid_size:] - mu[:, :grid_size]) / FD
+            obj = obj + float(monotonic_penalty_weight) * float(interval) * torch.relu(-slope).mean(dim=1)
         finite = torch.isfinite(obj.detach())
         ok = finite & live
         nan_run = torch.where(finite | ~live, torch.zeros_like(nan_run), nan_run + 1)
@@ -284,6 +394,11 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
             m.model.eval()
             m.likelihood.eval()
             m.is_fitted = True
+    if return_state:
+        state = FitManyState(params={k: v.detach().clone() for k, v in params.items()}, m1=m1, m2=m2, step=step, lr=lr, best=best,
+                             num_bad=num_bad, cooldown=cooldown, es_best=es_best, stale=stale, live=live, last_obj=last_obj,
+                             last_iteration=last_iteration, iterations_done=torch.tensor(it0 + iterations))
+        return last_obj, state
     return last_obj
 
 
@@ -360,4 +475,4 @@ def predict_many(models, covariates_list):
     return results
 
 
-__all__ = ["fit_many", "predict_many"]
+__all__ = ["fit_many", "predict_many", "FitManyState"]

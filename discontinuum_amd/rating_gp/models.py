@@ -162,6 +162,7 @@ class _MonotonicPenalty:
     (gpytorch.py:130-187).  With ``interval`` > 1 only every interval-th call is evaluated and weighted by it."""
 
     FD = 1e-3
+    uniforms = None  # test hook: callable(m) -> (2, m) uniforms in [0, 1) replacing the random draw
 
     def __init__(self, engine, grid_size, interval):
         self.engine, self.m, self.interval, self.calls = engine, int(grid_size), int(interval), 0
@@ -173,9 +174,10 @@ class _MonotonicPenalty:
         if self.interval > 1 and self.calls % self.interval:
             return torch.zeros((), device=dev, dtype=dt)
         lo, hi = eng.dm.X.min(axis=0), eng.dm.X.max(axis=0)
-        t = lo[TIME] + torch.rand((self.m,), dtype=dt, device=dev) * (hi[TIME] - lo[TIME])
+        u = (self.uniforms(self.m).to(dev, dt) if self.uniforms is not None else torch.rand((2, self.m), dtype=dt, device=dev))
+        t = lo[TIME] + u[0] * (hi[TIME] - lo[TIME])
         log_lo, log_hi = float(np.log(lo[STAGE] + 1e-6)), float(np.log(hi[STAGE] + 1e-6))
-        s = torch.exp(log_lo + torch.rand((self.m,), dtype=dt, device=dev) * (log_hi - log_lo))
+        s = torch.exp(log_lo + u[1] * (log_hi - log_lo))
         here = torch.stack([t, s], dim=1)
         there = torch.stack([t, s + self.FD], dim=1)
         mu = eng._differentiable_mean(torch.cat([here, there]))  # both point sets through one solve

@@ -352,3 +352,94 @@ def test_predict_many_matches_per_site_predict(family, gpu_device):
         assert np.allclose(t_b.values, t_s.values, rtol=1e-9) and np.allclose(se_b.values, se_s.values, rtol=1e-9)
         assert list(t_b.coords) == list(t_s.coords)
     assert np.allclose(alone[0][0].values, both[0][0].values, rtol=1e-9)
+
+
+def test_fit_many_monotonic_penalty_follows_the_single_site_trajectories(gpu_device):
+    """The rating-gp monotonicity penalty inside ``fit_many`` -- every site's differentiable posterior mean through ONE
+    batched ``dgp_predict_mean`` / ``dgp_mean_vjp`` per iteration -- against ``RatingGP.fit(monotonic_penalty_weight=...)``
+    per site, on the SAME penalty grids (both draw their uniforms from a per-site, per-call table here)."""
+    from discontinuum_amd.multisite_fit import fit_many
+    from discontinuum_amd.rating_gp import RatingGP
+    from discontinuum_amd.rating_gp import models as rmod
+
+    class Seeded(RatingGP):
+        seed = 0
+
+        def build_model(self, *args):
+            torch.manual_seed(self.seed)
+            return super().build_model(*args)
+
+    sizes, iters, m, weight = [70, 48, 96], 25, 16, 5.0
+    data = []
+    for i, k in enumerate(sizes):  # a rating that BENDS DOWN over the upper half of the stages: the penalty is active
+        cov, tgt, unc = rating_dataset(k, seed=500 + i)
+        stage = cov["stage"].values
+        bent = tgt.values * np.exp(-1.5 * np.maximum(stage - np.median(stage), 0.0) ** 2)
+        data.append((cov, type(tgt)(bent, dims=tgt.dims, coords={"time": tgt.coords["time"]}, name=tgt.name, attrs=dict(tgt.attrs)), unc))
+    table = torch.rand((len(sizes), iters, 2, m), dtype=torch.float64, generator=torch.Generator().manual_seed(11))
+
+    def new(i):
+        mod = Seeded()
+        mod.seed = 900 + i
+        return mod
+
+    solo, penalties = [], []
+    try:
+        for i, (cov, tgt, unc) in enumerate(data):
+            calls = {"k": 0}
+
+            def draw(mm, i=i, calls=calls):
+                calls["k"] += 1
+                return table[i, calls["k"] - 1]
+
+            rmod._MonotonicPenalty.uniforms = staticmethod(draw)
+            mod = new(i)
+            mod.fit(cov, tgt, target_unc=unc, iterations=iters, monotonic_penalty_weight=weight, grid_size=m)
+            solo.append(mod)
+    finally:
+        rmod._MonotonicPenalty.uniforms = None
+    calls = {"k": 0}
+
+    def draw_all(mm):
+        calls["k"] += 1
+        return table[:, calls["k"] - 1]
+
+    many = [new(i) for i in range(len(sizes))]
+    final = fit_many(many, data, iterations=iters, monotonic_penalty_weight=weight, grid_size=m, _penalty_uniforms=draw_all)
+    assert bool(torch.isfinite(final).all()) and calls["k"] == iters
+    plain = [new(i) for i in range(len(sizes))]
+    fit_many(plain, data, iterations=iters)
+    for a, b, c in zip(solo, many, plain):
+        pa = torch.cat([p.detach().reshape(-1) for p in a.model.parameters()])
+        pb = torch.cat([p.detach().reshape(-1) for p in b.model.parameters()])
+        pc = torch.cat([p.detach().reshape(-1) for p in c.model.parameters()])
+        assert (pa - pb).abs().max() < 1e-5, (pa - pb).abs().max()
+        assert (pb - pc).abs().max() > 1e-4  # the penalty does steer the fit
+
+
+def test_fit_many_resume_continues_the_run(gpu_device):
+    """40 iterations in one call = 25 + 15 through ``return_state`` / ``resume`` (optimiser moments, learning rates, plateau
+    and early-stopping counters travel in ``FitManyState``; its dictionary form survives ``torch.save`` / ``weights_only``)."""
+    import io
+
+    from discontinuum_amd.loadest_gp import LoadestGP
+    from discontinuum_amd.multisite_fit import FitManyState, fit_many
+
+    sizes = [80, 64, 120]
+    data = [loadest_dataset(k, seed=40 + i) for i, k in enumerate(sizes)]
+    a = [LoadestGP() for _ in sizes]
+    fa = fit_many(a, data, iterations=40)
+    b = [LoadestGP() for _ in sizes]
+    _, st = fit_many(b, data, iterations=25, return_state=True)
+    buf = io.BytesIO()
+    torch.save(st.as_dict(), buf)
+    buf.seek(0)
+    st2 = FitManyState.from_dict(torch.load(buf, weights_only=True))
+    fb = fit_many(b, data, iterations=15, resume=st2)
+    assert torch.equal(fa, fb)
+    for x, y in zip(a, b):
+        px = torch.cat([p.detach().reshape(-1) for p in x.model.parameters()])
+        py = torch.cat([p.detach().reshape(-1) for p in y.model.parameters()])
+        assert torch.equal(px, py)
+    with pytest.raises(ValueError):
+        fit_many([LoadestGP()], data[:1], iterations=1, resume=st)
