@@ -1,8 +1,10 @@
 // dgp_api.hip -- the C ABI declared in include/dgp_hip.h: plan bookkeeping and stage sequencing.
+#include <mutex>
 #include <new>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
 #include <vector>
 
 #include "../../include/dgp_hip.h"
@@ -197,9 +199,7 @@ int dgp_plan_destroy(dgp_plan* p) {
     for (int i = 0; i < p->nsev; ++i) (void)hipEventDestroy(p->sev[i]);
     delete[] p->sev;
   }
-  if (p->s2) (void)hipStreamDestroy(p->s2);
-  if (p->sc) (void)hipStreamDestroy(p->sc);
-  if (p->s3) (void)hipStreamDestroy(p->s3);
+  // s2 / sc / s3 belong to the caller-stream's StreamSet (process lifetime), not to the plan
   if (p->have_xev)
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(p->xev[i]);
   p->ring.destroy();
@@ -312,14 +312,49 @@ int dgp_plan_buffer(const dgp_plan* p, int which, void** dev_ptr, int64_t* ld) {
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
-static int ensure_async(dgp_plan* p) {
-  if (!p->lookahead || p->s2) return 0;
-  // the bulk trailing updates run at the LOWEST priority so that the latency-critical panel chain on
-  // the caller's stream gets the CUs first whenever both have workgroups ready
+// The library's internal streams belong to the CALLER'S stream, not to a plan: every plan driven from one stream (the
+// usual case: torch's current stream) uses the same three -- bulk updates (lowest priority), rest of the split panel
+// chain (highest), early inverse (lowest).  A process has few hardware queues (4 by default); streams beyond that share
+// one, and kernels of streams that share a queue run one after the other.  With a stream set per PLAN, a process that had
+// created a second plan found the rest stream of the split chain behind the bulk stream in one queue: the critical
+// kernels then wait for whole bulk launches (measured: a single n = 8192 fit went from 12.3 to 20 ms as soon as a batched
+// plan existed in the process).  Plans driven from DIFFERENT streams (sites.py::fit_sites) still get a set each.  The
+// streams live as long as the process.
+struct StreamSet {
+  hipStream_t bulk = nullptr, rest = nullptr, early = nullptr;
+};
+static StreamSet* stream_set(hipStream_t caller) {
+  static std::mutex mtx;
+  static std::vector<std::pair<std::pair<int, hipStream_t>, StreamSet*>> sets;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mtx);
+  for (auto& e : sets)
+    if (e.first.first == dev && e.first.second == caller) return e.second;
+  StreamSet* st = new (std::nothrow) StreamSet();
+  if (!st) return nullptr;
+  sets.push_back({{dev, caller}, st});
+  return st;
+}
+static int make_stream(hipStream_t* out, bool high) {
+  if (*out) return 0;
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  hipError_t e = hipStreamCreateWithPriority(&p->s2, hipStreamNonBlocking, least);
-  if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithPriority");
+  hipError_t e = hipStreamCreateWithPriority(out, hipStreamNonBlocking, high ? greatest : least);
+  return e == hipSuccess ? 0 : hipfail(e, "hipStreamCreateWithPriority");
+}
+
+static int ensure_async(dgp_plan* p, hipStream_t s) {
+  if (!p->lookahead) return 0;
+  // the bulk trailing updates run at the LOWEST priority so that the latency-critical panel chain on
+  // the caller's stream gets the CUs first whenever both have workgroups ready
+  StreamSet* st = stream_set(s);
+  if (!st) return fail(DGP_E_ARG, "out of host memory");
+  int rc = make_stream(&st->bulk, false);
+  if (rc) return rc;
+  p->s2 = st->bulk;
+  if (p->ev) return 0;
+  hipError_t e;
   p->nev = 3 * (int)(p->N / DGP_TILE_HOST);  // group-ahead schedule: P, U; split chain: ED, ER, U
   p->ev = new (std::nothrow) hipEvent_t[p->nev];
   if (!p->ev) return fail(DGP_E_ARG, "out of host memory");
@@ -350,12 +385,13 @@ static int split_start(const dgp_plan* p) {
   while (k + 4 <= nbk && (long)(nbk - k - 3) * (nbk - k - 2) / 2 > cap) k += 2;
   return k;
 }
-static int ensure_split(dgp_plan* p) {
-  if (!split_applies(p) || p->sc) return 0;
-  int least = 0, greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  hipError_t e = hipStreamCreateWithPriority(&p->sc, hipStreamNonBlocking, greatest);
-  if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithPriority");
+static int ensure_split(dgp_plan* p, hipStream_t s) {
+  if (!split_applies(p)) return 0;
+  StreamSet* st = stream_set(s);
+  if (!st) return fail(DGP_E_ARG, "out of host memory");
+  const int rc = make_stream(&st->rest, true);
+  if (rc) return rc;
+  p->sc = st->rest;
   return 0;
 }
 
@@ -368,12 +404,15 @@ static bool early_applies(const dgp_plan* p) {
   const int nbk = (int)(p->N / DGP_TILE_HOST);
   return p->early && p->lookahead >= 2 && nbk >= 16 && nbk <= 80;
 }
-static int ensure_early(dgp_plan* p) {
-  if (!early_applies(p) || p->s3) return 0;  // an idle extra stream is not free either (n = 32768: 293 -> 305 ms)
-  int least = 0, greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  hipError_t e = hipStreamCreateWithPriority(&p->s3, hipStreamNonBlocking, least);
-  if (e != hipSuccess) return hipfail(e, "hipStreamCreateWithPriority");
+static int ensure_early(dgp_plan* p, hipStream_t s) {
+  if (!early_applies(p)) return 0;  // an idle extra stream is not free either (n = 32768: 293 -> 305 ms)
+  StreamSet* st = stream_set(s);
+  if (!st) return fail(DGP_E_ARG, "out of host memory");
+  const int rc = make_stream(&st->early, false);
+  if (rc) return rc;
+  p->s3 = st->early;
+  if (p->have_xev) return 0;
+  hipError_t e;
   for (int i = 0; i < 8; ++i) {
     e = hipEventCreateWithFlags(&p->xev[i], hipEventDisableTiming);
     if (e != hipSuccess) return hipfail(e, "hipEventCreateWithFlags");
@@ -502,9 +541,9 @@ static int run_gram(dgp_plan* p, const double* theta, const void* noise, hipStre
 }
 template <typename T>
 static int run_potrf(dgp_plan* p, hipStream_t s) {
-  int rc = ensure_async(p);
+  int rc = ensure_async(p, s);
   if (rc) return rc;
-  if ((rc = ensure_timing(p)) || (rc = ensure_split(p))) return rc;
+  if ((rc = ensure_timing(p)) || (rc = ensure_split(p, s))) return rc;
   if (split_applies(p) && p->sc)
     return potrf_split<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, (T*)p->snap, s, p->sc, p->s2, p->ev,
                           p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr, split_start(p));
@@ -539,7 +578,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
   tick(p, TS_GRAM, 0, s);
   if ((rc = run_gram<T>(p, theta, noise, s))) return rc;
   tick(p, TS_GRAM, 1, s);
-  if ((rc = ensure_async(p)) || (rc = ensure_early(p))) return rc;
+  if ((rc = ensure_async(p, s)) || (rc = ensure_early(p, s))) return rc;
   tick(p, TS_POTRF, 0, s);
   const int nbk = (int)(p->N / DGP_TILE_HOST);
   const bool early = early_applies(p) && p->s3 != nullptr;
@@ -570,7 +609,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
                                       EARLY_RESERVED_CUS);
       if (rc && !e->rc) e->rc = rc;
     };
-    if ((rc = ensure_timing(p)) || (rc = ensure_split(p))) return rc;
+    if ((rc = ensure_timing(p)) || (rc = ensure_split(p, s))) return rc;
     if (split_applies(p) && p->sc)
       rc = potrf_split<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, (T*)p->snap, s, p->sc, p->s2, p->ev,
                           p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx, split_start(p));
