@@ -37,7 +37,13 @@ struct Prefetch {
 // sequential panel chain, so it uses 64-row tiles: twice the workgroups, half the per-workgroup latency.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T* __restrict__ Tinv, long ld, int k,
-                                                      long bs) {
+                                                      long bs, const int* __restrict__ wait_word = nullptr, int wait_value = 0) {
+  if (wait_word) {  // split panel chain: launched on the rest stream BEFORE diag(k) has finished; see potrf_split
+    if (threadIdx.x == 0)
+      while (__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_value) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   A = site(A, bs);
   Tinv = site(Tinv, bs);
   // 64 rows x all 128 panel columns per workgroup: a workgroup only ever reads the rows it overwrites
@@ -158,7 +164,7 @@ static bool f32_diag64() {
 }
 template <typename TS, typename TC>
 static void launch_diag_as(TS* A, long N, long k0, TS* Tinv, TS* logdet, int* info, hipStream_t s, Batch bt, bool init,
-                           double* logdet_hi) {
+                           double* logdet_hi, int done_index, int done_value) {
   static bool configured = false;
   const size_t bytes = potrf_diag_fast_smem<TC>();
   if (!configured) {
@@ -167,7 +173,8 @@ static void launch_diag_as(TS* A, long N, long k0, TS* Tinv, TS* logdet, int* in
     configured = true;
   }
   potrf_diag_fast_kernel<TS, TC><<<dim3(1, 1, (unsigned)bt.B), 256, bytes, s>>>(
-      A, N, k0, Tinv, logdet, info, bt.ws, bt.ws * (long)sizeof(TS) / (long)sizeof(int), init ? 1 : 0, POTRF_INFO_INTS, logdet_hi);
+      A, N, k0, Tinv, logdet, info, bt.ws, bt.ws * (long)sizeof(TS) / (long)sizeof(int), init ? 1 : 0, POTRF_INFO_INTS, logdet_hi,
+      done_index, done_value);
 }
 // the fp32 plans' unrounded log-determinant lives in the scalar block right behind (log-det, quad): element 2..3 as ONE double
 template <typename T>
@@ -175,11 +182,12 @@ static double* logdet_hi_slot(T* logdet) {
   return sizeof(T) == 4 ? reinterpret_cast<double*>(logdet + 2) : nullptr;
 }
 template <typename T>
-static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hipStream_t s, Batch bt, bool init = false) {
+static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hipStream_t s, Batch bt, bool init = false,
+                        int done_index = -1, int done_value = 0) {
   if (sizeof(T) == 4 && f32_diag64())
-    launch_diag_as<T, double>(A, N, k0, Tinv, logdet, info, s, bt, init, logdet_hi_slot(logdet));
+    launch_diag_as<T, double>(A, N, k0, Tinv, logdet, info, s, bt, init, logdet_hi_slot(logdet), done_index, done_value);
   else
-    launch_diag_as<T, T>(A, N, k0, Tinv, logdet, info, s, bt, init, logdet_hi_slot(logdet));
+    launch_diag_as<T, T>(A, N, k0, Tinv, logdet, info, s, bt, init, logdet_hi_slot(logdet), done_index, done_value);
 }
 
 template <typename T>
@@ -445,16 +453,10 @@ struct ChainJobs {
   ChainJob j[2];
 };
 template <typename T>
-__global__ __launch_bounds__(256, 2) void chain_col_kernel(T* __restrict__ A, long ld, int nbk, ChainJobs jobs,
-                                                           T* __restrict__ snap) {
+__device__ __forceinline__ void chain_col_tile(T* __restrict__ A, long ld, const ChainJob& jb, long row0, long col0,
+                                               T* __restrict__ snap, T* __restrict__ smem) {
   using G = TileGemm<T, true, true, 64, 64>;
-  __shared__ T smem[G::SMEM_ELEMS];
-  __builtin_amdgcn_s_setprio(3);
-  const ChainJob jb = jobs.j[blockIdx.z];
-  const long row0 = (long)jb.row_lo * NB + (long)blockIdx.x * 64;
-  if (row0 >= (long)nbk * NB) return;
-  const long col0 = (long)jb.jc * NB + (long)blockIdx.y * 64;
-  if (col0 > row0 + 63) return;  // strictly upper 64 x 64 quadrant of the diagonal block
+  {
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
   typename G::acc_t keep[G::MI][G::NI];
@@ -464,6 +466,30 @@ __global__ __launch_bounds__(256, 2) void chain_col_kernel(T* __restrict__ A, lo
   if (jb.snap_rb >= 0 && row0 / NB == jb.snap_rb) {
     T* sn = snap + (row0 - (long)jb.snap_rb * NB) * NB + (long)blockIdx.y * 64;
     G::foreach (acc, [&](int r, int c, T& v) { sn[(long)r * NB + c] = sizeof(T) == 8 ? -v : v; });
+  }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chain_col_kernel(T* __restrict__ A, long ld, int nbk, ChainJobs jobs,
+                                                           T* __restrict__ snap, int* __restrict__ info, int done_value) {
+  using G = TileGemm<T, true, true, 64, 64>;
+  __shared__ T smem[G::SMEM_ELEMS];
+  __builtin_amdgcn_s_setprio(3);
+  const ChainJob jb = jobs.j[blockIdx.z];
+  const long row0 = (long)jb.row_lo * NB + (long)blockIdx.x * 64;
+  const long col0 = (long)jb.jc * NB + (long)blockIdx.y * 64;
+  // (workgroups beyond the matrix or in the strictly upper 64 x 64 quadrant of a diagonal block only take their ticket)
+  if (row0 < (long)nbk * NB && col0 <= row0 + 63) chain_col_tile<T>(A, ld, jb, row0, col0, snap, smem);
+  // the LAST workgroup to finish publishes "R(k) is through" (flags[0] = done_value) for crit(k + 2): no signal launch
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
+    if (atomicAdd(&info[CHAIN_TICKET], 1) == total - 1) {
+      info[CHAIN_TICKET] = 0;
+      __hip_atomic_store(&info[CHAIN_FLAG0], done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -527,6 +553,12 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
     last_u = q;
   };
   if (k_start == 0) {
+    // The rest stream's first trsm polls info[CHAIN_DIAG_DONE], which still holds the LAST step's final value until this
+    // factorisation's first diagonal-block kernel resets the status words: clear it here, on s, and let c2 start behind
+    // that (one event per factorisation; without it trsm(0) could run ahead of diag(0) on stale data)
+    chain_signal_kernel<<<1, 64, 0, s>>>(info + CHAIN_DIAG_DONE, 0);
+    hipEventRecord(ED[0], s);
+    hipStreamWaitEvent(c2, ED[0], 0);
     snap_copy_kernel<T><<<8, 256, 0, s>>>(A, N, 1, 0, snap + (long)NB * NB);  // rows of block 1 of panel 0, before their trsm
   } else {
     // hand-over from the pair schedule after chain(q0 - 1): what R(k_start - 1) would have done except its trsm -- the
@@ -542,8 +574,7 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
     ChainJobs jobs;
     jobs.j[0] = ChainJob{k + 1, k + 2, k - 1, 2, k + 2};
     jobs.j[1] = ChainJob{k + 2, k + 2, k - 1, 2, -1};
-    chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 2), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB);
-    chain_signal_kernel<<<1, 64, 0, c2>>>(flags, k + 1);
+    chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 2), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB, info, k + 1);
     hipEventRecord(ER[k], c2);
     chain_signal_kernel<<<1, 64, 0, s2>>>(flags + 1, q0 - 1);  // the pair schedule's bulk launches (0 .. q0 - 2) are through
     if (k + 3 < nbk) bulk(q0 - 1);
@@ -556,27 +587,27 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
       const int nfinal = (k & 1) ? 0 : ((k == k_start && k_start > 0) ? 2 : 1);
       crit_kernel<T><<<10, 256, cbytes, s>>>(A, N, k, Tinv, snap + (long)(k & 1) * NB * NB, nfinal, flags, need_rest, need_bulk);
     }
-    launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt, k == 0);
+    // diag(k) publishes info[CHAIN_DIAG_DONE] = k + 1 itself; the rest stream's trsm(k) is launched right away and polls
+    // that word: no event record / stream wait between the critical kernels (each costs the stream ~3 us)
+    launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt, k == 0, CHAIN_DIAG_DONE, k + 1);
     if (k + 1 >= nbk) break;
-    hipEventRecord(ED[k], s);
     // ---- rest stream
-    hipStreamWaitEvent(c2, ED[k], 0);
-    trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, 1), 256, 0, c2>>>(A, Tinv, N, k, 0);
+    trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, 1), 256, 0, c2>>>(A, Tinv, N, k, 0, info + CHAIN_DIAG_DONE, k + 1);
     const int q = k >> 1;
     ChainJobs jobs;
     if ((k & 1) == 0) {  // first panel of pair q: column k+1 (below its diagonal block) <- panel k; snapshot block row k+2
       jobs.j[0] = ChainJob{k + 1, k + 2, k, 1, k + 2};
       jobs.j[1] = jobs.j[0];
       if (k + 2 < nbk)
-        chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 1), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB);
+        chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 1), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB, info, k + 1);
     } else {             // second panel: columns k+1 (below its diagonal block; snapshot block row k+2) and k+2 (whole) <- pair q
       if (q >= 1) hipStreamWaitEvent(c2, U[q - 1], 0);
       jobs.j[0] = ChainJob{k + 1, k + 2, k - 1, 2, k + 2};
       jobs.j[1] = ChainJob{k + 2, k + 2, k - 1, 2, -1};
       if (k + 2 < nbk)
-        chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 2), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB);
+        chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 2), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB, info, k + 1);
     }
-    chain_signal_kernel<<<1, 64, 0, c2>>>(flags, k + 1);  // R(k) finished
+    if (k + 2 >= nbk) chain_signal_kernel<<<1, 64, 0, c2>>>(flags, k + 1);  // R(k) finished (otherwise chain_col's last workgroup says so)
     hipEventRecord(ER[k], c2);
     checkpoint(k + 1, c2);
     if ((k & 1) == 1 && k + 3 < nbk) bulk(q);  // released behind the chain's own updates

@@ -158,7 +158,8 @@ template <typename TS, typename T = TS>
 __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(TS* __restrict__ A, long ld, long k0,
                                                               TS* __restrict__ Tinv, TS* __restrict__ logdet,
                                                               int* __restrict__ info, long bs, long ibs, int init,
-                                                              int ninit, double* __restrict__ logdet_hi) {
+                                                              int ninit, double* __restrict__ logdet_hi, int done_index,
+                                                              int done_value) {
   A = site(A, bs);
   Tinv = site(Tinv, bs);
   logdet = site(logdet, bs);
@@ -319,6 +320,16 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(TS* __restrict__ A
     if (bad < 128) atomicCAS(info, 0, (int)(k0 + bad + 1));
   }
   DGP_DIAG_STAMP(7)
+  // split panel chain: publish "this block is factored" for the rest stream's trsm, which was launched before this
+  // kernel finished and polls the word (no event record / stream wait on the critical stream).  Every thread's stores of
+  // L and L^-1 precede the barrier; the release makes them visible to the agent.
+  if (done_index >= 0) {
+    __syncthreads();
+    if (t == 0) {
+      __threadfence();
+      __hip_atomic_store(&info[done_index], done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 template <typename T>

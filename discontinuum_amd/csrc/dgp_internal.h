@@ -83,8 +83,10 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready_blocks, TrtriProgre
 // info[0] = potrf status; info[EARLY_CTR0 + 2i ..] = (tile queue, worker count) of the i-th early inverse launch
 #define CHAIN_FLAG0 2  /* info[2], info[3]: the split chain's progress counters (rest steps / bulk launches finished) */
 #define EARLY_CTR0 4
-#define EARLY_CTR_PAIRS 126
-#define POTRF_INFO_INTS (EARLY_CTR0 + 2 * EARLY_CTR_PAIRS)
+#define EARLY_CTR_PAIRS 125
+#define POTRF_INFO_INTS (EARLY_CTR0 + 2 * EARLY_CTR_PAIRS + 2)
+#define CHAIN_DIAG_DONE (POTRF_INFO_INTS - 2)  /* diagonal blocks finished (split chain: the rest stream's trsm waits on it) */
+#define CHAIN_TICKET (POTRF_INFO_INTS - 1)     /* workgroup ticket of the rest stream's column-update kernel */
 // per-device table of compute units kept free of early-inverse workgroups (null if unavailable)
 const unsigned char* reserved_cu_table(int nreserve, int* n_cu);
 template <typename T>
