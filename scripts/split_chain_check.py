@@ -24,14 +24,17 @@ for n in ns:
         torch.cuda.synchronize()
         res[mode] = (out.cpu().clone(), torch.tril(p.buffer(_lib.BUF_A)).cpu().clone(), torch.tril(p.buffer(_lib.BUF_T)).cpu().clone())
         reps = 20 if n <= 8192 else 3
-        for _ in range(3):
+        for _ in range(5):
             p.fit_step(theta, rd, nd)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            out, a, dn = p.fit_step(theta, rd, nd)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / reps * 1e3
+        best = float("inf")
+        for _batch in range(4):  # best of four batches: the first steps after a plan is created / freed are erratic
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out, a, dn = p.fit_step(theta, rd, nd)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / reps * 1e3)
+        ms = best
         p.set_timing(True); p.fit_step(theta, rd, nd); torch.cuda.synchronize(); tm = p.get_timing()
         res[mode] += (ms, tm[_lib.TIME_POTRF])
         del p
