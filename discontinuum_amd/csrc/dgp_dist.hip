@@ -24,6 +24,7 @@
 // Flops per rank: N^3 / (3 world) each for L, L^-1 and K^^-1 -- the single-GPU fit step's N^3, divided by the ranks.
 #include <new>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/dgp_hip.h"
@@ -58,14 +59,53 @@ __global__ __launch_bounds__(256) void pack_kernel(const T* __restrict__ src, lo
 }
 
 // A[i, j] -= P[i, :] P[j, :]^T for the rank's block columns right of the group (pass 1).  P row 0 = global row c0.
+// One workgroup per LIVE tile: the rank's columns right of the group are enumerated group by group (W columns with
+// consecutive global indices bj0 + h, nbk - bj0 - h tiles each, from the diagonal down), so no workgroup is launched for
+// the half of a (rows x columns) rectangle that lies above the diagonal (n = 65536 fp32, one rank: 114.7 -> 116.9 TFLOP/s).
+struct SlabTiles {
+  int lg0, ngl, W, world, rank, nbk;
+  __host__ __device__ int group_tiles(int lg) const {  // tiles of local group lg (0 if it lies beyond the matrix)
+    const int bj0 = (lg * world + rank) * W;      // N is a multiple of the group width: a group is whole or absent
+    return bj0 < nbk ? W * (nbk - bj0) - W * (W - 1) / 2 : 0;
+  }
+  __host__ __device__ long total() const {
+    long t = 0;
+    for (int lg = lg0; lg < ngl; ++lg) t += group_tiles(lg);
+    return t;
+  }
+  __device__ bool decode(long t, int& lb, int& bi, int& bj) const {
+    for (int lg = lg0; lg < ngl; ++lg) {
+      const int c = group_tiles(lg);
+      if (t >= c) {
+        t -= c;
+        continue;
+      }
+      const int bj0 = (lg * world + rank) * W;
+      for (int h = 0; h < W; ++h) {
+        const int ch = nbk - bj0 - h;
+        if (t < ch) {
+          lb = lg * W + h;
+          bj = bj0 + h;
+          bi = bj + (int)t;
+          return true;
+        }
+        t -= ch;
+      }
+    }
+    return false;
+  }
+};
 template <typename T>
 __global__ __launch_bounds__(256, 2) void slab_syrk_kernel(T* __restrict__ Aslab, long Cl, const T* __restrict__ P, int GW,
-                                                           long c0, int nbk, SlabMap sm, int lb0, int cb, int ce) {
+                                                           long c0, SlabTiles st, int cb, int ce) {
   using G = TileGemm<T, true, true>;
   __shared__ T smem[G::SMEM_ELEMS];
-  const int lb = lb0 + (int)blockIdx.y, bj = sm.gblock(lb);
-  const int bi = (int)((c0 + GW) / NB) + (int)blockIdx.x;
-  if (bj >= nbk || bj < cb || bj >= ce || bi < bj) return;
+  int lb, bi, bj;
+  // plain order (a column's tiles follow each other, the hardware deals them round-robin over the XCDs, which then all read
+  // the same column operand): the XCD-contiguous remap of dgp_common.h gives every XCD its own column region and measured
+  // 84 instead of 117 TFLOP/s here; a row-major order measured the same 117
+  if (!st.decode((long)blockIdx.x, lb, bi, bj)) return;
+  if (bj < cb || bj >= ce) return;  // the lookahead split: this launch covers block columns [cb, ce) only
   typename G::acc_t acc[G::MI][G::NI];
   T* C = Aslab + (long)bi * NB * Cl + (long)lb * NB;
   typename G::acc_t keep[G::MI][G::NI];
@@ -285,10 +325,11 @@ static int dist_update(dgp_dist* p, int g, const void* panel, int cb, int ce, hi
   const long c0 = (long)g * p->GW;
   const int rows_below = p->nbk - (g + 1) * p->W;
   const int lg0 = p->owned_below(g + 1);  // first local group right of g
-  const int nlb = (p->ngl - lg0) * p->W;
-  if (rows_below <= 0 || nlb <= 0) return 0;
-  slab_syrk_kernel<T><<<dim3((unsigned)rows_below, (unsigned)nlb), 256, 0, s>>>((T*)p->A, p->Cl, (const T*)panel, (int)p->GW, c0,
-                                                                             p->nbk, p->sm(), lg0 * p->W, cb, ce);
+  if (rows_below <= 0 || lg0 >= p->ngl) return 0;
+  const SlabTiles st{lg0, p->ngl, p->W, p->world, p->rank, p->nbk};
+  const long tiles = st.total();
+  if (tiles <= 0) return 0;
+  slab_syrk_kernel<T><<<dim3((unsigned)tiles), 256, 0, s>>>((T*)p->A, p->Cl, (const T*)panel, (int)p->GW, c0, st, cb, ce);
   return (int)hipGetLastError();
 }
 
