@@ -21,7 +21,7 @@ forward -- done here once per iteration on the stacked parameters -- and a learn
 Early stopping is per site; the rating-gp monotonicity penalty (``monotonic_penalty_weight``) differentiates every
 site's posterior mean at its own random grid through ONE batched ``dgp_predict_mean`` / ``dgp_mean_vjp`` per iteration;
 ``return_state=True`` / ``resume=state`` continue a run where it stopped (optimiser moments, schedules, counters).
-Not supported here: AdamW, arbitrary penalty callbacks.
+Not supported here: arbitrary penalty callbacks.
 """
 from __future__ import annotations
 
@@ -166,7 +166,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
              scheduler: bool = True, progress: bool = False, early_stopping: bool = False,
              monotonic_penalty_weight: float = 0.0, grid_size: int = 64, monotonic_penalty_interval: int = 1,
              resume: FitManyState | None = None, return_state: bool = False, generator: torch.Generator | None = None,
-             _penalty_uniforms=None):
+             optimizer: str = "adam", _penalty_uniforms=None):
     """Fit ``models[i]`` to ``datasets[i] = (covariates, target[, target_unc])`` for all i at once.  Returns the
     per-site final objectives (a float64 tensor) -- with ``return_state=True`` the pair (objectives, ``FitManyState``);
     the models are updated in place (``is_fitted``, parameters, device state).
@@ -175,7 +175,11 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     posterior mean on a fresh random grid of ``grid_size`` points per iteration (every ``monotonic_penalty_interval``-th
     iteration, weighted by the interval), exactly the term of ``RatingGP.fit`` (src/rating_gp/models/gpytorch.py:130-187),
     for all sites through one batched launch sequence.  ``resume``: the state a previous call returned (same sites, same
-    order) -- ``iterations`` more iterations from there; ``generator`` seeds the penalty grids."""
+    order) -- ``iterations`` more iterations from there; ``generator`` seeds the penalty grids.  ``optimizer``: "adam"
+    (L2 weight decay 1e-4, the reference's default) or "adamw" (decoupled decay 1e-2), as ``MarginalHIP.fit``
+    (engines/gpytorch.py:268-286); the default learning rate argument applies to both."""
+    if optimizer not in ("adam", "adamw"):
+        raise ValueError(f"Unsupported optimizer: {optimizer!r}. Supported optimizers are 'adam' and 'adamw'.")
     if len(models) != len(datasets) or not models:
         raise ValueError("fit_many needs one (covariates, target) pair per model")
     B = len(models)
@@ -280,7 +284,8 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     step = torch.zeros(B, dtype=torch.float64)
     m1 = {k: torch.zeros_like(v) for k, v in params.items()}
     m2 = {k: torch.zeros_like(v) for k, v in params.items()}
-    beta1, beta2, eps, wd = 0.9, 0.999, 1e-8, 1e-4
+    beta1, beta2, eps, wd = 0.9, 0.999, 1e-8, (1e-4 if optimizer == "adam" else 1e-2)
+    decoupled = optimizer == "adamw"
     best = torch.full((B,), float("inf"), dtype=torch.float64)
     num_bad = torch.zeros(B, dtype=torch.float64)
     cooldown = torch.zeros(B, dtype=torch.float64)
@@ -348,8 +353,12 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
         bc2 = 1.0 - beta2 ** step
         with torch.no_grad():
             for k, p in params.items():
-                g = grads[k] * per_site(p, coef) + wd * p
                 mk = per_site(p, okf)
+                if decoupled:  # torch.optim.AdamW: p *= 1 - lr wd first, the moments see the bare gradient
+                    g = grads[k] * per_site(p, coef)
+                    p.mul_(torch.where(mk > 0, 1.0 - per_site(p, lr) * wd, torch.ones_like(mk)))
+                else:
+                    g = grads[k] * per_site(p, coef) + wd * p
                 m1[k] = torch.where(mk > 0, beta1 * m1[k] + (1 - beta1) * g, m1[k])
                 m2[k] = torch.where(mk > 0, beta2 * m2[k] + (1 - beta2) * g * g, m2[k])
                 denom = torch.sqrt(m2[k]) / per_site(p, torch.sqrt(torch.clamp(bc2, min=1e-300))) + eps

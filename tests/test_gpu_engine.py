@@ -443,3 +443,29 @@ def test_fit_many_resume_continues_the_run(gpu_device):
         assert torch.equal(px, py)
     with pytest.raises(ValueError):
         fit_many([LoadestGP()], data[:1], iterations=1, resume=st)
+
+
+def test_fit_many_adamw_follows_the_single_site_trajectories(gpu_device):
+    """``fit_many(optimizer="adamw")`` (decoupled weight decay 1e-2) against ``model.fit(optimizer="adamw")`` per site."""
+    from discontinuum_amd.loadest_gp import LoadestGP
+    from discontinuum_amd.multisite_fit import fit_many
+
+    sizes, iters = [90, 64, 130], 30
+    data = [loadest_dataset(k, seed=320 + i) for i, k in enumerate(sizes)]
+    solo = []
+    for cov, tgt in data:
+        m = LoadestGP()
+        m.fit(cov, tgt, iterations=iters, optimizer="adamw")
+        solo.append(m)
+    many = [LoadestGP() for _ in sizes]
+    fit_many(many, data, iterations=iters, optimizer="adamw")
+    ref = [LoadestGP() for _ in sizes]
+    fit_many(ref, data, iterations=iters)
+    for a, b, c in zip(solo, many, ref):
+        pa = torch.cat([p.detach().reshape(-1) for p in a.model.parameters()])
+        pb = torch.cat([p.detach().reshape(-1) for p in b.model.parameters()])
+        pc = torch.cat([p.detach().reshape(-1) for p in c.model.parameters()])
+        assert (pa - pb).abs().max() < 1e-6, (pa - pb).abs().max()
+        assert (pb - pc).abs().max() > 1e-5  # and it is not the Adam trajectory
+    with pytest.raises(ValueError):
+        fit_many(many, data, iterations=1, optimizer="sgd")
