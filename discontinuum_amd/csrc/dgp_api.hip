@@ -365,14 +365,14 @@ static int ensure_async(dgp_plan* p, hipStream_t s) {
   return 0;
 }
 
-// The split panel chain (critical tile on the caller's stream, rest of the chain on `sc`): one site, pairs of panels,
-// i.e. below the size from which group_size() switches to larger groups because the bulk updates bound the factorisation.
+// The split panel chain (critical tile on the caller's stream, rest of the chain on `sc`): one site.  Large matrices start in the
+// group schedule (groups of 2 / 4 / 8 panels, group_size()) and hand over for their chain-bound tail (split_start()).
 // DGP_SPLIT_CHAIN=0 selects the single-stream chain (A/B measurements, the bitwise-equality tests); read at every call.
 static bool split_applies(const dgp_plan* p) {
   const char* e = getenv("DGP_SPLIT_CHAIN");
   if (e && atoi(e) == 0) return false;
   const long nbk = p->N / DGP_TILE_HOST;
-  return p->B == 1 && p->lookahead && nbk >= 4 && group_size(p->lookahead, p->B, nbk) == 2;
+  return p->B == 1 && p->lookahead && nbk >= 4 && group_size(p->lookahead, p->B, nbk) % 2 == 0;  // (DGP_GROUP may ask for odd groups)
 }
 // first block column of the split chain: the earliest even k from which a bulk launch (all tiles right of the pair) is at
 // most DGP_SPLIT_TILES tiles (default 768 = 1.5 rounds of the 512 workgroup slots): before that the factorisation is bound
@@ -546,7 +546,7 @@ static int run_potrf(dgp_plan* p, hipStream_t s) {
   if ((rc = ensure_timing(p)) || (rc = ensure_split(p, s))) return rc;
   if (split_applies(p) && p->sc)
     return potrf_split<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, (T*)p->snap, s, p->sc, p->s2, p->ev,
-                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr, split_start(p));
+                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr, split_start(p), group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST));
   return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), s, p->s2, p->ev,
                   p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr,
                   batch_of<T>(p));
@@ -612,7 +612,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
     if ((rc = ensure_timing(p)) || (rc = ensure_split(p, s))) return rc;
     if (split_applies(p) && p->sc)
       rc = potrf_split<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, (T*)p->snap, s, p->sc, p->s2, p->ev,
-                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx, split_start(p));
+                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx, split_start(p), group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST));
     else
       rc = potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), s, p->s2, p->ev,
                     p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx);

@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256) void snap_copy_kernel(const T* __restrict__ A,
 // LDS: X as 36 sub-blocks of 16 x 17 (lower block triangle) + the tile's four 16-row strips of HALF of P (16 sub-blocks).
 template <typename T>
 __global__ __launch_bounds__(256) void crit_kernel(T* __restrict__ A, long ld, int k, const T* __restrict__ Tinv,
-                                                   const T* __restrict__ snap, int nfinal, const int* __restrict__ flags,
-                                                   int need_rest, int need_bulk) {
+                                                   const T* __restrict__ snap, int nfinal, int first_final, int solve_,
+                                                   const int* __restrict__ flags, int need_rest, int need_bulk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char crit_smem[];
   using acc_t = typename Mfma<T>::acc_t;
   T* sX = reinterpret_cast<T*>(crit_smem);   // DGP_DTRI sub-blocks
@@ -356,9 +356,10 @@ __global__ __launch_bounds__(256) void crit_kernel(T* __restrict__ A, long ld, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = Csub[(long)Mfma<T>::crow(lane, r) * ld + (lane & 15)];
   // ---- everything this kernel reads from global memory is requested up front
-  // nfinal = panels whose rows of this block are FINAL in A (0: odd block, 1: even block -- panel k-2 --, 2: the first
-  // block after the hand-over from the pair schedule, whose panel k-1 was solved there: no snapshot, no trsm here)
-  const bool solve = nfinal < 2;
+  // nfinal panels from first_final on have FINAL rows in A and are applied first (0: odd block; 1: even block, panel k-2;
+  // G: the first block after the hand-over from a schedule with groups of G panels, which solved all of them: no
+  // snapshot, no trsm here -- solve_ = 0); then panel k-1 from the snapshot (solve_ = 1)
+  const bool solve = solve_ != 0;
   T xreg[DGP_DTRI];  // X = L_{k-1,k-1}^-1, lower block triangle
   T af[DGP_DNB][4];  // this wave's 16 rows of the snapshot as MFMA A fragments
   if (solve) {
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void crit_kernel(T* __restrict__ A, long ld, i
     (void)half;
   };
   for (int f = 0; f < nfinal; ++f) {  // panels k-2 (, k-1): final rows of L, this wave's strip straight into LDS (lane = one column of a half)
-    const T* Pg = A + ((long)k * NB + srow) * ld + (long)(k - 2 + f) * NB + lane;
+    const T* Pg = A + ((long)k * NB + srow) * ld + (long)(first_final + f) * NB + lane;
     T pr[2][16];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -493,18 +494,20 @@ __global__ __launch_bounds__(256, 2) void chain_col_kernel(T* __restrict__ A, lo
   }
 }
 
-// k_start (even): the block columns before it are factored by the single-stream pair schedule (potrf with q_stop) --
+// k_start (a multiple of G_old): the block columns before it are factored by the single-stream GROUP schedule (potrf with q_stop,
+// groups of G_old panels: pairs below 96 block columns, 4 or 8 above) --
 // while a bulk launch is many rounds long the factorisation is bound by it, and crit's ten workgroups would queue behind
 // it like every other chain kernel -- and the split chain takes over from there.
 template <typename T>
 int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_t s, hipStream_t c2, hipStream_t s2,
                 hipEvent_t* ev /* 3 nbk */, hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop, int nck, const int* ck_blocks,
-                hipEvent_t* ck_ev, void (*on_ck)(void*, int), void* ck_ctx, int k_start) {
+                hipEvent_t* ck_ev, void (*on_ck)(void*, int), void* ck_ctx, int k_start, int G_old) {
   const int nbk = (int)(N / NB);
+  if (G_old < 2) G_old = 2;
   if (k_start < 0) k_start = 0;
-  k_start &= ~1;
+  k_start = (k_start + G_old - 1) / G_old * G_old;  // a group boundary of the schedule that runs first (G_old is even)
   if (k_start + 4 > nbk)  // nothing left for the split chain
-    return potrf<T>(A, N, Tinv, logdet, info, 2, s, s2, ev, syrk_ev, n_syrk, syrk_flop, nck, ck_blocks, ck_ev, on_ck, ck_ctx);
+    return potrf<T>(A, N, Tinv, logdet, info, G_old, s, s2, ev, syrk_ev, n_syrk, syrk_flop, nck, ck_blocks, ck_ev, on_ck, ck_ctx);
   PotrfCarry carry;
   const Batch bt;
   hipEvent_t* ED = ev;            // diag(k) done, on s
@@ -521,8 +524,8 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
   double flop = 0.0;
   int* flags = info + CHAIN_FLAG0;  // zeroed with the other status words by the first diagonal-block kernel
   if (k_start > 0) {
-    const int q0 = k_start / 2;
-    const int rc = potrf<T>(A, N, Tinv, logdet, info, 2, s, s2, ev, syrk_ev, n_syrk, syrk_flop, nck, ck_blocks, ck_ev, on_ck,
+    const int q0 = k_start / G_old;
+    const int rc = potrf<T>(A, N, Tinv, logdet, info, G_old, s, s2, ev, syrk_ev, n_syrk, syrk_flop, nck, ck_blocks, ck_ev, on_ck,
                             ck_ctx, Batch(), q0, &carry);
     if (rc) return rc;
     ck_next = carry.ck_next;
@@ -539,14 +542,17 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
   auto tri = [](int m) { return (unsigned)(m * (m + 1) / 2); };
   const double tile_flop = 2.0 * NB * NB * NB;
   auto bulk_exists = [&](int q) { return q >= 0 && 2 * q + 4 < nbk; };
-  auto bulk = [&](int q) {  // block columns >= 2q + 4 <- pair q, behind the rest step recorded in ER[2q + 1]
+  // block columns >= 2q + 4 <- panels kfirst .. kfirst + nk - 1 (pair q: kfirst = 2q, nk = 2; at the hand-over the last
+  // group of the schedule that ran first), behind the rest step recorded in ER[2q + 1]
+  auto bulk = [&](int q, int kfirst = -1, int nk = 2) {
     const int k = 2 * q + 1;
+    if (kfirst < 0) kfirst = k - 1;
     hipStreamWaitEvent(s2, ER[k], 0);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
     const SyrkShape sh((int)tri(nbk - k - 3), 512);
-    syrk_kernel<T><<<dim3(sh.grid, 1, 1), 256, 0, s2>>>(A, N, k - 1, 2, k + 3, sh.nfull, sh.split, 0);
+    syrk_kernel<T><<<dim3(sh.grid, 1, 1), 256, 0, s2>>>(A, N, kfirst, nk, k + 3, sh.nfull, sh.split, 0);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
-    flop += 2.0 * tile_flop * tri(nbk - k - 3);
+    flop += (double)nk * tile_flop * tri(nbk - k - 3);
     ++ns;
     chain_signal_kernel<<<1, 64, 0, s2>>>(flags + 1, q + 1);  // bulk(q) finished
     hipEventRecord(U[q], s2);
@@ -561,10 +567,11 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
     hipStreamWaitEvent(c2, ED[0], 0);
     snap_copy_kernel<T><<<8, 256, 0, s>>>(A, N, 1, 0, snap + (long)NB * NB);  // rows of block 1 of panel 0, before their trsm
   } else {
-    // hand-over from the pair schedule after chain(q0 - 1): what R(k_start - 1) would have done except its trsm -- the
-    // chain's own two columns <- pair q0 - 1, the snapshot for crit(k_start + 1) -- then the counters and bulk(q0 - 1)
-    const int k = k_start - 1, q0 = k_start / 2;
-    hipEvent_t* Uold = ev + nbk;  // the pair schedule's U events (its P events are ev[0 .. q0))
+    // hand-over from the group schedule after its chain(q0 - 1): what R(k_start - 1) would have done except its trsm -- the
+    // chain's own two columns <- the last group (G_old panels), the snapshot for crit(k_start + 1) -- then the counters and
+    // that group's bulk update of the columns from k_start + 2 on
+    const int k = k_start - 1, q0 = k_start / G_old;
+    hipEvent_t* Uold = ev + nbk;  // the group schedule's U events (its P events are ev[0 .. q0))
     hipEventRecord(ED[k_start], s);  // any free slot of ED: the chain of the pair schedule ends here
     hipStreamWaitEvent(c2, ED[k_start], 0);
     if (q0 >= 2) {
@@ -572,20 +579,22 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
       hipStreamWaitEvent(s2, Uold[q0 - 2], 0);
     }
     ChainJobs jobs;
-    jobs.j[0] = ChainJob{k + 1, k + 2, k - 1, 2, k + 2};
-    jobs.j[1] = ChainJob{k + 2, k + 2, k - 1, 2, -1};
+    jobs.j[0] = ChainJob{k + 1, k + 2, k_start - G_old, G_old, k + 2};
+    jobs.j[1] = ChainJob{k + 2, k + 2, k_start - G_old, G_old, -1};
     chain_col_kernel<T><<<dim3(2 * (nbk - k - 2), 2, 2), 256, 0, c2>>>(A, N, nbk, jobs, snap + (long)((k + 2) & 1) * NB * NB, info, k + 1);
     hipEventRecord(ER[k], c2);
-    chain_signal_kernel<<<1, 64, 0, s2>>>(flags + 1, q0 - 1);  // the pair schedule's bulk launches (0 .. q0 - 2) are through
-    if (k + 3 < nbk) bulk(q0 - 1);
+    chain_signal_kernel<<<1, 64, 0, s2>>>(flags + 1, k_start / 2 - 1);  // the group schedule's bulk launches are through
+    if (k + 3 < nbk) bulk(k_start / 2 - 1, k_start - G_old, G_old);
   }
   for (int k = k_start; k < nbk; ++k) {
     // ---- critical stream
     if (k >= 1) {
       // crit(k) needs R(k-2) and, for an even block, bulk(k/2 - 2): checked inside the kernel (flags), not by stream waits
       const int need_rest = k >= 2 ? k - 1 : 0, need_bulk = ((k & 1) == 0 && k >= 4 && bulk_exists(k / 2 - 2)) ? k / 2 - 1 : 0;
-      const int nfinal = (k & 1) ? 0 : ((k == k_start && k_start > 0) ? 2 : 1);
-      crit_kernel<T><<<10, 256, cbytes, s>>>(A, N, k, Tinv, snap + (long)(k & 1) * NB * NB, nfinal, flags, need_rest, need_bulk);
+      const bool handed = k == k_start && k_start > 0;  // every pending panel of this block was solved by the group schedule
+      const int nfinal = handed ? G_old : ((k & 1) ? 0 : 1), first_final = handed ? k_start - G_old : k - 2;
+      crit_kernel<T><<<10, 256, cbytes, s>>>(A, N, k, Tinv, snap + (long)(k & 1) * NB * NB, nfinal, first_final, handed ? 0 : 1, flags,
+                                            need_rest, need_bulk);
     }
     // diag(k) publishes info[CHAIN_DIAG_DONE] = k + 1 itself; the rest stream's trsm(k) is launched right away and polls
     // that word: no event record / stream wait between the critical kernels (each costs the stream ~3 us)
@@ -1230,7 +1239,7 @@ int sample_draws(const T* L, long M, const T* Z, long Q, const T* mean, int m, i
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \
                         const int*, hipEvent_t*, void (*)(void*, int), void*, Batch, int, PotrfCarry*);                                                                                        \
   template int potrf_split<T>(T*, long, T*, T*, int*, T*, hipStream_t, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, \
-                              int, const int*, hipEvent_t*, void (*)(void*, int), void*, int);                       \
+                              int, const int*, hipEvent_t*, void (*)(void*, int), void*, int, int);                       \
   template int potrf_group<T>(T*, long, int, T*, T*, int*, int, int, hipStream_t);                                \
   template int trtri_advance<T>(const T*, long, T*, T*, int, TrtriProgress*, hipStream_t, int, int*, int, int, Batch, long);                   \
   template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t, Batch, long);                                        \

@@ -69,7 +69,8 @@ template <typename T>
 int potrf_split(T* A, long N, T* Dinv, T* logdet, int* info, T* snap, hipStream_t s, hipStream_t c2, hipStream_t s2,
                 hipEvent_t* ev, hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop, int nck = 0,
                 const int* ck_blocks = nullptr, hipEvent_t* ck_ev = nullptr, void (*on_ck)(void* ctx, int idx) = nullptr,
-                void* ck_ctx = nullptr, int k_start = 0 /* even: block columns before it by the single-stream schedule */);
+                void* ck_ctx = nullptr, int k_start = 0 /* block columns before it by the single-stream group schedule */,
+                int G_old = 2 /* panels per group of that schedule */);
 // progress of the level recursion of trtri when it is issued piecewise (trtri_advance)
 struct TrtriProgress {
   static constexpr int MAXLVL = 16;

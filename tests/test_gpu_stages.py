@@ -345,7 +345,9 @@ def test_early_inverse_matches_in_order_schedule(n, gpu_device):
 @pytest.mark.parametrize("model,d,n,split_tiles", [("loadest", 3, 500, None), ("loadest", 3, 512, None), ("rating", 2, 640, None),
                                                    ("loadest", 3, 1000, None), ("loadest", 2, 2048, None), ("rating", 2, 3300, None),
                                                    # hand-over from the pair schedule to the split chain after 2, 6, 12 pairs
-                                                   ("loadest", 3, 2500, 120), ("loadest", 3, 3300, 60), ("rating", 2, 3072, 21)])
+                                                   ("loadest", 3, 2500, 120), ("loadest", 3, 3300, 60), ("rating", 2, 3072, 21),
+                                                   # hand-over from GROUPS OF FOUR panels (what plans of 96+ block columns start in)
+                                                   ("loadest", 3, 3300, -60), ("loadest", 3, 12288, None)])
 def test_split_panel_chain_is_bitwise_the_single_stream_chain(model, d, n, split_tiles, gpu_device, monkeypatch):
     """The split panel chain (critical tile on the caller's stream, rest of the chain on a second stream, in-kernel progress
     counters; csrc/dgp_chol.hip::potrf_split) applies every panel to every element in the same order and continues the same
@@ -357,7 +359,9 @@ def test_split_panel_chain_is_bitwise_the_single_stream_chain(model, d, n, split
     dev = gpu_device
     X, r, noise, theta = make_case(model, d, n, seed=n, perturb=0.1)
     if split_tiles is not None:
-        monkeypatch.setenv("DGP_SPLIT_TILES", str(split_tiles))
+        monkeypatch.setenv("DGP_SPLIT_TILES", str(abs(split_tiles)))
+        if split_tiles < 0:
+            monkeypatch.setenv("DGP_GROUP", "4")
     res = {}
     for mode, level in (("0", 1), ("1", 1), ("1", 2), ("1", 1)):
         monkeypatch.setenv("DGP_SPLIT_CHAIN", mode)
