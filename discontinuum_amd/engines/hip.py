@@ -480,16 +480,21 @@ class MarginalHIP(BaseModel):
         bar = tqdm.tqdm(range(iterations - first), ncols=100, desc=f"Training {first}->{iterations}")
         best, stale, bad_in_a_row, i = float("inf"), 0, 0, 0
         use_penalty = penalty_callback is not None and penalty_weight > 0.0
-        # the iteration's host algebra in closed form where the model allows it (gp/explicit.py); the penalty term is
-        # an autograd expression, so it keeps the autograd path
-        explicit = None if (use_penalty or not self.explicit_host_algebra) else ExplicitObjective.build(self, mll._priors)
+        # the iteration's host algebra in closed form where the model allows it (gp/explicit.py); a penalty joins that
+        # path if it brings its own closed form (``explicit_terms``: rating-gp's monotonicity penalty does), any other
+        # penalty callback is an autograd expression and keeps the autograd path
+        closed_penalty = use_penalty and hasattr(penalty_callback, "explicit_terms")
+        explicit = (ExplicitObjective.build(self, mll._priors)
+                    if self.explicit_host_algebra and (not use_penalty or closed_penalty) else None)
         try:
             for i in bar:
                 self._current_iteration = first + i
                 optimizer_obj.zero_grad(set_to_none=True)
                 try:
                     if explicit is not None:
-                        objective = torch.tensor([explicit.evaluate(set_grads=False)], dtype=torch.float64)
+                        objective = torch.tensor([explicit.evaluate(
+                            set_grads=False, penalty=penalty_callback if use_penalty else None,
+                            penalty_weight=float(penalty_weight) if use_penalty else 0.0)], dtype=torch.float64)
                     else:
                         objective = -mll(self._prior(), self._train_y)
                 except Exception:
@@ -498,7 +503,9 @@ class MarginalHIP(BaseModel):
                         raise
                     continue
                 penalty = None
-                if use_penalty:
+                if use_penalty and explicit is not None:
+                    penalty = None if explicit.last_penalty is None else torch.tensor(explicit.last_penalty, dtype=torch.float64)
+                elif use_penalty:
                     try:
                         value = penalty_callback()
                         penalty = value if torch.is_tensor(value) else None

@@ -211,10 +211,16 @@ class ExplicitObjective:
                 return
         raise NotPSDError(f"Matrix not positive definite: Cholesky pivot {int(row[_lib.OUT_INFO])} is not positive")
 
-    def evaluate(self, set_grads=True):
+    def evaluate(self, set_grads=True, penalty=None, penalty_weight=0.0):
         """One objective evaluation: launches the device step, leaves d objective / d raw of all parameters in
         ``flat_grad`` (and as ``p.grad`` of every parameter unless ``set_grads`` is False), returns the value (a
-        float).  Same arithmetic as ``-mll(model(train_x), train_y)`` + ``backward()``."""
+        float).  Same arithmetic as ``-mll(model(train_x), train_y)`` + ``backward()``.
+
+        ``penalty``: an object with ``explicit_terms(objective, x) -> (value, d value / d x)`` in the space of the
+        constrained values ``x`` (rating-gp's monotonicity penalty): ``penalty_weight * value`` joins the objective and
+        its gradient the flat gradient -- evaluated right after the fit step, on the factorisation it left in the plan.
+        A penalty that raises is skipped for this evaluation (the autograd loop does the same); ``last_penalty`` keeps
+        the value (None if skipped)."""
         eng = self.engine
         with torch.no_grad():
             r, noise = self.shortcut.residual_and_noise(eng._plan, eng._train_y)
@@ -228,9 +234,20 @@ class ExplicitObjective:
         np.add.at(gx, self.theta_src, row[_lib.OUT_DTHETA:_lib.OUT_DTHETA + self.ntheta])
         np.add.at(gx, self.shortcut_src, np.asarray([float(v) for v in self.shortcut.grads(row)]))
         self.flat_grad = gx * slope / n  # d objective / d raw, all parameters, in ``params`` order
+        value = (float(row[_lib.OUT_NLL]) - lp) / n
+        self.last_penalty = None
+        if penalty is not None and penalty_weight:
+            try:
+                pv, pgx = penalty.explicit_terms(self, x)
+            except Exception:  # noqa: BLE001
+                pv = None
+            if pv is not None:
+                self.last_penalty = float(pv)
+                value += float(penalty_weight) * float(pv)
+                self.flat_grad = self.flat_grad + float(penalty_weight) * pgx * slope
         if set_grads:
             self.assign_param_grads()
-        return (float(row[_lib.OUT_NLL]) - lp) / n
+        return value
 
     def assign_param_grads(self):
         """``p.grad`` of every parameter as views of the flat gradient of the last ``evaluate``."""

@@ -149,6 +149,7 @@ class _PowerLawShortcut(MeanShortcut):
         shifted = self.stage - c
         weights = torch.stack([torch.log(shifted), torch.reciprocal(shifted)])
         plan.set_dr_weights(weights)
+        self.weights = weights
         return target - a - b * weights[0], self.fixed_noise + float(self.second.detach())
 
     def grads(self, row):
@@ -184,6 +185,52 @@ class _MonotonicPenalty:
         slope = (mu[self.m:] - mu[: self.m]) / self.FD
         penalty = torch.relu(-slope).mean()
         return penalty * float(self.interval) if self.interval > 1 else penalty
+
+
+    def explicit_terms(self, obj, x):
+        """The same penalty for the closed-form training loop (``gp/explicit.py::ExplicitObjective.evaluate``): value and
+        gradient with respect to the CONSTRAINED values ``x`` (hyperparameters by ``obj.theta_src``; a, b, c and the learned
+        noise by ``obj.shortcut_src``), without autograd: one ``dgp_predict_mean``, the slope / relu / mean on the host,
+        one ``dgp_mean_vjp`` for d pen / d mu -> (d theta, d r, d noise), and the power law's chain rule in closed form
+        (r = y - a - b log(s - c): the reductions ``_PowerLawShortcut.grads`` reads from a result row, here formed from
+        this VJP's dr / dnoise; plus the prior mean's own part at the grid points)."""
+        eng, sc = self.engine, obj.shortcut
+        dev, dt = eng._train_x.device, eng.dtype
+        self.calls += 1
+        zero = np.zeros_like(x)
+        if self.interval > 1 and self.calls % self.interval:
+            return 0.0, zero
+        lo, hi = eng.dm.X.min(axis=0), eng.dm.X.max(axis=0)
+        u = (self.uniforms(self.m).to(torch.float64).cpu().numpy() if self.uniforms is not None
+             else torch.rand((2, self.m), dtype=torch.float64).numpy())
+        t = lo[TIME] + u[0] * (hi[TIME] - lo[TIME])
+        log_lo, log_hi = float(np.log(lo[STAGE] + 1e-6)), float(np.log(hi[STAGE] + 1e-6))
+        st = np.exp(log_lo + u[1] * (log_hi - log_lo))
+        grid = np.concatenate([np.stack([t, st], axis=1), np.stack([t, st + self.FD], axis=1)])
+        pw = sc.powerlaw
+        pw.clamp_c(min(sc.stage_min, float(grid[:, STAGE].min())))  # gpytorch's eval-mode forward sees the test stages too
+        a, b, c = (float(v.detach()) for v in (pw.a, pw.b, pw.c))
+        theta = x[obj.theta_src].tolist()
+        xg = torch.tensor(grid, dtype=dt, device=dev)
+        mu = eng._plan.predict_mean(theta, xg).to("cpu", torch.float64).numpy() + a + b * np.log(grid[:, STAGE] - c)
+        m = self.m
+        slope = (mu[m:] - mu[:m]) / self.FD
+        scale = float(self.interval) if self.interval > 1 else 1.0
+        value = scale * float(np.maximum(-slope, 0.0).mean())
+        dslope = np.where(slope < 0.0, -scale / m, 0.0)          # d value / d slope
+        w = np.concatenate([-dslope, dslope]) / self.FD           # d value / d mu
+        if not w.any():
+            return value, zero
+        dtheta, dr, dnoise = eng._plan.mean_vjp(theta, xg, torch.tensor(w, dtype=dt, device=dev))
+        wts = sc.weights                                          # (2, n): log(s - c), 1 / (s - c) of the training stages
+        red = torch.cat([dr.sum().reshape(1), wts @ dr, dnoise.sum().reshape(1), dtheta.reshape(-1)]).to("cpu", torch.float64).numpy()
+        gx = zero
+        np.add.at(gx, obj.theta_src, red[4:4 + len(obj.theta_src)])
+        shifted = grid[:, STAGE] - c
+        direct = np.asarray([w.sum(), float(w @ np.log(shifted)), -b * float(w @ (1.0 / shifted)), 0.0])
+        through_r = np.asarray([-red[0], -red[1], b * red[2], red[3]])
+        np.add.at(gx, obj.shortcut_src, direct + through_r)
+        return value, gx
 
 
 class RatingDataMixin(DataMixin):

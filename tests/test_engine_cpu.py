@@ -476,3 +476,40 @@ def test_parameter_names_follow_the_reference_module_trees():
     sd = r.model.state_dict()
     assert "covar_module.kernels.1.kernels.0.sigmoid_kernel.raw_b" in sd
     assert [k for k, _ in r.likelihood.named_parameters()] == ["second_noise_covar.raw_noise"]
+
+
+def test_closed_form_monotonic_penalty_matches_the_autograd_penalty(monkeypatch):
+    """rating-gp's monotonicity penalty inside the closed-form training loop (``_MonotonicPenalty.explicit_terms``: one
+    predict_mean + one mean_vjp, power-law chain rule by hand) against the autograd expression of the same penalty
+    (``_differentiable_mean``), on identical penalty grids and a rating that bends down (so that the penalty is ACTIVE):
+    same trajectory (parameters 1e-9 after 25 iterations), and not the trajectory of a fit without penalty."""
+    from discontinuum_amd.engines.hip import MarginalHIP
+    from discontinuum_amd.rating_gp import models as rmod
+
+    cov, tgt, unc = rating_dataset(70, seed=3)
+    stage = cov["stage"].values
+    bent = tgt.values * np.exp(-1.5 * np.maximum(stage - np.median(stage), 0.0) ** 2)
+    tgt = type(tgt)(bent, dims=tgt.dims, coords={"time": tgt.coords["time"]}, name=tgt.name, attrs=dict(tgt.attrs))
+    iters, m = 25, 12
+    table = torch.rand((iters + 2, 2, m), dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+
+    def run(explicit, weight):
+        calls = {"k": 0}
+
+        def draw(mm):
+            calls["k"] += 1
+            return table[calls["k"] - 1]
+
+        monkeypatch.setattr(rmod._MonotonicPenalty, "uniforms", staticmethod(draw))
+        monkeypatch.setattr(MarginalHIP, "explicit_host_algebra", explicit)
+        torch.manual_seed(7)
+        mod = RatingGP()
+        mod.fit(cov, tgt, target_unc=unc, iterations=iters, monotonic_penalty_weight=weight, grid_size=m, scheduler=False)
+        return torch.cat([p.detach().reshape(-1) for p in mod.model.parameters()]), calls["k"]
+
+    p_auto, k_auto = run(False, 4.0)
+    p_closed, k_closed = run(True, 4.0)
+    p_plain, _ = run(True, 0.0)
+    assert k_auto == iters and k_closed == iters
+    assert (p_auto - p_closed).abs().max() < 1e-9, (p_auto - p_closed).abs().max()
+    assert (p_closed - p_plain).abs().max() > 1e-4
