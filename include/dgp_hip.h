@@ -57,7 +57,8 @@ extern "C" {
 #define DGP_BUF_Z 4     /* L^-1 r */
 #define DGP_BUF_ALPHA 5 /* K^^-1 r */
 #define DGP_BUF_INFO 6  /* int32: info of the last factorisation */
-#define DGP_BUF_SCAL 7  /* scalars: [0] log|K^| accumulated by the diagonal-block kernels, [1] r^T K^^-1 r */
+#define DGP_BUF_SCAL 7  /* scalars: [0] log|K^| accumulated by the diagonal-block kernels, [1] r^T K^^-1 r; float32 plans also keep
+                           both UNROUNDED as doubles at elements [2..3] and [4..5] (the NLL's three terms are added in double) */
 
 typedef struct dgp_plan dgp_plan;
 
@@ -107,11 +108,14 @@ int dgp_plan_set_workspace(dgp_plan* plan, void* dev_ptr, size_t bytes);
  * dr and dnoise itself.  The vectors are read when the step runs; NULL clears.  Batched plans: [batch][2][n]. */
 int dgp_plan_set_dr_weights(dgp_plan* plan, const void* w_dev);
 /* Concurrency inside one fit step.  0: everything in order on the caller's stream.  1: the bulk trailing
- * updates of the factorisation run on a second (lowest-priority) stream beside the panel chain.  2 (default):
- * additionally the inverse's level recursion is issued on a third stream behind checkpoints of the
- * factorisation, filling the CUs its sequential tail leaves idle -- best for ONE plan per GPU; callers that keep
- * several plans in flight on one GPU should select 1 (the other plans already fill the idle CUs, and every
- * extra stream costs throughput there). */
+ * updates of the factorisation run on a second (lowest-priority) stream beside the panel chain, and -- single-site
+ * plans -- the chain itself is split: the next diagonal block's own rows and tile on the caller's stream, the rest of
+ * the chain on a third (highest-priority) stream.  2 (default): additionally the inverse's level recursion is issued
+ * on another stream behind checkpoints of the factorisation, filling the CUs its sequential tail leaves idle -- best
+ * for ONE plan per GPU; callers that keep several plans in flight on one GPU should select 1 (the other plans already
+ * fill the idle CUs).  The internal streams belong to the CALLER's stream: every plan driven from one stream shares
+ * one set (a process has few hardware queues), plans driven from different streams get a set each; they live as long
+ * as the process.  Results are ordered on the caller's stream whatever the level. */
 int dgp_plan_set_lookahead(dgp_plan* plan, int level);
 int dgp_plan_buffer(const dgp_plan* plan, int which, void** dev_ptr, int64_t* ld);
 
