@@ -214,11 +214,14 @@ class GPPlan:
 
     def posterior_cov(self, theta, Xs: torch.Tensor):
         """(K*^T alpha, latent posterior covariance K** - V^T V) at Xs (m, d): the covariance as an (M, M) tensor,
-        M = padded m, lower triangle valid (diagonal 128-blocks complete), identity pad -- ``dgp_posterior_cov``."""
-        if self.batch != 1:
-            raise ValueError("posterior_cov needs a plain (unbatched) plan")
-        th = _theta_array(theta, self.ntheta)
-        m = Xs.shape[0]
+        M = padded m, lower triangle valid (diagonal 128-blocks complete), identity pad -- ``dgp_posterior_cov``.
+        Batched plans: Xs (batch, m, d), theta (batch, ntheta) -> mean (batch, m), cov (batch, M, M), one launch sequence."""
+        lead = () if self.batch == 1 else (self.batch,)
+        if not (torch.is_tensor(Xs) and Xs.is_cuda and Xs.dtype == self.dtype and Xs.dim() == 2 + len(lead)
+                and Xs.shape[-1] == self.d and tuple(Xs.shape[:-2]) == lead):
+            raise ValueError(f"Xs must be a {lead + ('m', self.d)} {self.dtype} CUDA tensor")
+        th = _theta_array(theta, self.ntheta * self.batch)
+        m = Xs.shape[-2]
         M = int(self.lib.dgp_padded_n(m))
         with torch.cuda.device(self.device):
             xs = Xs.contiguous()
@@ -227,8 +230,8 @@ class GPPlan:
                 self._pred_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
             base = self._pred_ws.data_ptr()
             base += (-base) % 256
-            mean = torch.empty(m, dtype=self.dtype, device=self.device)
-            cov = torch.empty(M, M, dtype=self.dtype, device=self.device)
+            mean = torch.empty(lead + (m,), dtype=self.dtype, device=self.device)
+            cov = torch.empty(lead + (M, M), dtype=self.dtype, device=self.device)
             _lib.check(
                 self.lib.dgp_posterior_cov(self._h, th, _ptr(xs), m, C.c_void_p(base), need, _ptr(mean), _ptr(cov), _stream()),
                 "dgp_posterior_cov",

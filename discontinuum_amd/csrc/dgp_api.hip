@@ -745,10 +745,14 @@ static int post_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t m,
   long wbs;
   int rc = predict_common<T>(p, theta, Xs, m, work, mean, &V, &Xst, &vpad, &wbs, s);
   if (rc) return rc;
-  hipError_t he = hipMemsetAsync(vpad, 0, sizeof(T) * M, s);  // zero "noise" for K(Xs, Xs)
+  // zero "noise" for K(Xs, Xs); a batched plan's sites keep theirs at the work area's site stride
+  hipError_t he = hipMemset2DAsync(vpad, sizeof(T) * (size_t)(wbs > 0 ? wbs : M), 0, sizeof(T) * M, (size_t)p->B, s);
   if (he != hipSuccess) return (int)he;
-  if ((rc = gram_sym<T>(p->model, p->d, Xst, M, (int)m, theta, vpad, (T*)cov, s))) return rc;
-  return posterior_cov<T>(V, p->N, M, (T*)cov, s);
+  Batch wb;
+  wb.B = p->B;
+  wb.ws = wbs;
+  if ((rc = gram_sym<T>(p->model, p->d, Xst, M, (int)m, theta, vpad, (T*)cov, s, wb, p->pre, nullptr, M * M, wbs, true))) return rc;
+  return posterior_cov<T>(V, p->N, M, (T*)cov, s, p->B, wbs);
 }
 
 struct VjpLayout {
@@ -889,7 +893,6 @@ int dgp_predict(dgp_plan* p, const double* theta, const void* Xs, int64_t m, voi
 int dgp_posterior_cov(dgp_plan* p, const double* theta, const void* Xs, int64_t m, void* work, size_t work_bytes,
                       void* mean, void* cov, void* stream) {
   DGP_CHECK_PLAN(p);
-  DGP_SINGLE_SITE(p);
   if (!theta || !Xs || !work || !mean || !cov || m <= 0) return fail(DGP_E_ARG, "dgp_posterior_cov: null argument");
   if (!p->have_factor) return fail(DGP_E_STATE, "dgp_posterior_cov: no factorisation in the plan (call dgp_factorize)");
   if (work_bytes < dgp_predict_workspace_bytes(p, m)) return fail(DGP_E_WORKSPACE, "dgp_posterior_cov: workspace too small");

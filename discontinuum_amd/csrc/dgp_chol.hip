@@ -1183,9 +1183,11 @@ int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, 
 
 // cov[i,j] = Kss[i,j] - sum_k V[k,i] V[k,j]  (i >= j tiles), k over all N rows of V (N x M)
 template <typename T>
-__global__ __launch_bounds__(256, 2) void posterior_cov_kernel(const T* __restrict__ V, long N, long M, T* __restrict__ cov) {
+__global__ __launch_bounds__(256, 2) void posterior_cov_kernel(const T* __restrict__ V, long N, long M, T* __restrict__ cov, long wbs) {
   using G = TileGemm<T, false, false>;
   __shared__ T smem[G::SMEM_ELEMS];
+  V = site(V, wbs);  // batched plans: V in the caller's work area, cov [batch][M][M]
+  cov = site(cov, M * M);
   int bi, bj;
   tri_decode(blockIdx.x, bi, bj);
   typename G::acc_t acc[G::MI][G::NI];
@@ -1197,9 +1199,9 @@ __global__ __launch_bounds__(256, 2) void posterior_cov_kernel(const T* __restri
 }
 
 template <typename T>
-int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s) {
+int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s, int B, long wbs) {
   const int nb = (int)(M / NB);
-  posterior_cov_kernel<T><<<(unsigned)(nb * (nb + 1) / 2), 256, 0, s>>>(V, N, M, cov);
+  posterior_cov_kernel<T><<<dim3((unsigned)(nb * (nb + 1) / 2), 1, (unsigned)B), 256, 0, s>>>(V, N, M, cov, wbs);
   return (int)hipGetLastError();
 }
 
@@ -1233,7 +1235,7 @@ int sample_draws(const T* L, long M, const T* Z, long Q, const T* mean, int m, i
 }
 
 #define DGP_INST(T)                                                                                              \
-  template int posterior_cov<T>(const T*, long, long, T*, hipStream_t);                                          \
+  template int posterior_cov<T>(const T*, long, long, T*, hipStream_t, int, long);                                          \
   template int sample_draws<T>(const T*, long, const T*, long, const T*, int, int, T*, hipStream_t);             \
   template int symv_lower<T>(const T*, long, const T*, int, const T*, T*, T*, T*, hipStream_t, Batch, long);     \
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \

@@ -136,11 +136,11 @@ __device__ __forceinline__ void load4<float>(const float* src, float (&v)[4]) {
 template <typename T, typename M>
 __global__ __launch_bounds__(256) void gram_sym_kernel(const T* __restrict__ Xt, long N, int n, const PreBatch<M> pb,
                                                        const T* __restrict__ noise, T* __restrict__ K, long bs,
-                                                       const int* __restrict__ ns) {
+                                                       const int* __restrict__ ns, long ks, long noise_stride) {
   const typename M::Pre& pre = pb.get();
   Xt = site(Xt, bs);
-  K = site(K, bs);
-  noise = site(noise, (long)n);
+  K = site(K, ks);
+  noise = site(noise, noise_stride);
   n = site_n(ns, n);
   __shared__ T sfi[M::NF][64], sfj[M::NF][64];
   int bi, bj;
@@ -562,13 +562,15 @@ int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s, Batch bt) {
 
 template <typename T>
 int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s,
-             Batch bt, void* pre_scratch, void* pre_staging) {
+             Batch bt, void* pre_scratch, void* pre_staging, long k_stride, long noise_stride, bool pre_ready) {
   const int nt = model_ntheta(model, d);
   if (nt < 0) return -2;
   const long nb = N / 64;
   const unsigned grid = (unsigned)(nb * (nb + 1) / 2);
+  const long ks = k_stride >= 0 ? k_stride : bt.ws, nstr = noise_stride >= 0 ? noise_stride : (long)n;
   DGP_DISPATCH_MODEL(model, d, (gram_sym_kernel<T, M><<<dim3(grid, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
-                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, true, s, pre_staging), noise, K, bt.ws, bt.ns)));
+                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, !pre_ready, s, pre_staging), noise, K, bt.ws, bt.ns,
+                                   ks, nstr)));
   return (int)hipGetLastError();
 }
 
@@ -674,7 +676,7 @@ int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream
 
 #define DGP_INST(T)                                                                                              \
   template int pack_x<T>(const T*, int, int, long, T*, hipStream_t, Batch);                                      \
-  template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t, Batch, void*, void*); \
+  template int gram_sym<T>(int, int, const T*, long, int, const double*, const T*, T*, hipStream_t, Batch, void*, void*, long, long, bool); \
   template int gram_cross<T>(int, int, const T*, long, int, const T*, long, int, const double*, T*, hipStream_t, Batch, long, void*, void*); \
   template int gram_diag<T>(int, int, const T*, long, int, const double*, T*, hipStream_t, Batch, long, void*);    \
   template int gram_grad<T>(int, int, const T*, long, int, const double*, const T*, const T*, T*, T*, hipStream_t, Batch, \

@@ -28,7 +28,9 @@ int pack_x(const T* X, int n, int d, long N, T* Xt, hipStream_t s, Batch bt = Ba
 template <typename T>
 int gram_sym(int model, int d, const T* Xt, long N, int n, const double* theta, const T* noise, T* K, hipStream_t s,
              Batch bt = Batch(), void* pre_scratch = nullptr /* pre_scratch_bytes(B) of device memory, B > 8 */,
-             void* pre_staging = nullptr /* pinned host memory of the same size that outlives the copy, or null: blocking copy */);
+             void* pre_staging = nullptr /* pinned host memory of the same size that outlives the copy, or null: blocking copy */,
+             long k_stride = -1 /* site stride of K (default bt.ws) */, long noise_stride = -1 /* of noise (default n) */,
+             bool pre_ready = false /* pre_scratch already holds this theta (gram_cross of the same call) */);
 // The inference launchers take a Batch like the fit-step ones (gridDim.z = sites): training-side arrays at the plan's
 // site stride bt.ws, everything in the caller's work area (test coordinates, cross Gram, partials ...) at `wbs` elements.
 template <typename T>
@@ -128,7 +130,7 @@ int symv_lower(const T* S, long N, const T* g, int n, const T* alpha, T* beta, T
                Batch bt = Batch(), long wbs = 0);
 // cov (M x M) = Kss - V^T V, lower tiles; Kss already holds K(Xs, Xs) (identity pad)
 template <typename T>
-int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s);
+int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s, int B = 1, long wbs = 0);
 
 // out (ndraw x m) = mean + (L Z)^T : L is M x M lower (identity pad), Z is M x Q standard normals, Q % 128 == 0
 template <typename T>

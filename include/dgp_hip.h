@@ -89,11 +89,12 @@ size_t dgp_plan_workspace_bytes(const dgp_plan* plan);
  * the sequential panel chain and the launch rate over the batch (the reference analogue is its map over sites,
  * examples/nwqn-loadest-example/nwqn-loadest-example.py:156-159).  The workspace grows by the same factor and the
  * arrays of dgp_set_inputs / dgp_fit_step / dgp_factorize become batch-major: X[batch][n][d], theta[batch][ntheta],
- * r / noise / dr / dnoise [batch][n], out[batch][DGP_OUT_LEN].  dgp_predict, dgp_predict_mean and dgp_mean_vjp also accept
- * batched plans: every site works at its own m points -- Xs[batch][m][d], theta[batch][ntheta] -> mean / var [batch][m];
- * dgp_mean_vjp: w[batch][m] -> dtheta[batch][ntheta], dr / dnoise [batch][n] -- with ONE launch sequence for all sites
- * (gridDim.z = batch, like the fit step); their work areas are batch times the single-site size (the *_workspace_bytes
- * queries account for it).  dgp_posterior_cov and dgp_cross_gram need batch == 1. */
+ * r / noise / dr / dnoise [batch][n], out[batch][DGP_OUT_LEN].  dgp_predict, dgp_posterior_cov, dgp_predict_mean and
+ * dgp_mean_vjp also accept batched plans: every site works at its own m points -- Xs[batch][m][d], theta[batch][ntheta]
+ * -> mean / var [batch][m], cov [batch][M][M]; dgp_mean_vjp: w[batch][m] -> dtheta[batch][ntheta], dr / dnoise [batch][n]
+ * -- with ONE launch sequence for all sites (gridDim.z = batch, like the fit step); their work areas are batch times the
+ * single-site size (the *_workspace_bytes queries account for it).  The stage-level entries dgp_stage_grad and
+ * dgp_cross_gram need batch == 1. */
 int dgp_plan_set_batch(dgp_plan* plan, int batch);
 int dgp_plan_batch(const dgp_plan* plan);
 /* Ragged batches (after dgp_plan_set_workspace, before dgp_set_inputs): site b has sizes[b] <= n observations; it

@@ -53,6 +53,52 @@ def test_posterior_cov_fp64(model, d, n, m, gpu_device):
     assert torch.equal(mean2, mean) and torch.equal(_lower(cov2, m), _lower(cov, m))
 
 
+@pytest.mark.parametrize("model,d,sizes,m", [
+    ("loadest", 3, (300, 300, 300), 130), ("rating", 2, (260, 200, 131), 300),
+    ("loadest", 2, (200, 150, 128, 200, 90, 200, 177, 200, 64, 200), 70),  # > 8 sites: hyperparameters through the device scratch
+])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_posterior_cov_of_a_batched_plan(model, d, sizes, m, dtype, gpu_device):
+    """dgp_posterior_cov on a (ragged) batched plan -- one launch sequence, cov [batch][M][M] -- site by site against the
+    oracle (fp64: the single plan's tolerances; fp32: mean 1e-3, covariance 2e-3 of its largest entry) and against a
+    single-site plan holding site 0 (1e-12 / 1e-4 relative)."""
+    from discontinuum_amd.backend import GPPlan
+
+    dev, B, n = gpu_device, len(sizes), max(sizes)
+    f64 = dtype == torch.float64
+    cases = [make_case(model, d, nb, seed=60 + b, perturb=0.2) for b, nb in enumerate(sizes)]
+    X = torch.zeros(B, n, d, dtype=torch.float64)
+    r = torch.zeros(B, n, dtype=torch.float64)
+    noise = torch.ones(B, n, dtype=torch.float64)
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        X[b, :nb], r[b, :nb], noise[b, :nb] = c[0], c[1], c[2]
+    theta = torch.stack([c[3] for c in cases])
+    Xs = torch.stack([make_case(model, d, m, seed=80 + b)[0] for b in range(B)])
+    pb = GPPlan(model, n, d, dtype=dtype, device=dev, lookahead=1, batch=B)
+    pb.set_site_sizes(sizes)
+    pb.set_inputs(X.to(dev, dtype).contiguous())
+    pb.factorize(theta, r.to(dev, dtype).contiguous(), noise.to(dev, dtype).contiguous())
+    mean, cov = pb.posterior_cov(theta, Xs.to(dev, dtype))
+    M = cov.shape[-1]
+    assert mean.shape == (B, m) and cov.shape == (B, M, M)
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        mu_ref, cov_ref = orc.posterior(model, c[0], c[1], c[2], c[3], Xs[b], full_cov=True)
+        scale = cov_ref.abs().max()
+        assert (mean[b].cpu().double() - mu_ref).abs().max() < (1e-9 if f64 else 1e-3)
+        assert (_lower(cov[b], m) - torch.tril(cov_ref)).abs().max() <= (1e-8 if f64 else 2e-3) * scale
+        if M > m:
+            pad = cov[b, m:, :].cpu()
+            assert torch.equal(torch.tril(pad[:, m:]), torch.eye(M - m, dtype=dtype)) and pad[:, :m].abs().max() == 0
+    # site 0 (a full-size one) alone in a single-site plan: same kernels, same tile order
+    ps = GPPlan(model, n, d, dtype=dtype, device=dev, lookahead=1)
+    ps.set_inputs(X[0].to(dev, dtype).contiguous())
+    ps.factorize(theta[0], r[0].to(dev, dtype).contiguous(), noise[0].to(dev, dtype).contiguous())
+    mean1, cov1 = ps.posterior_cov(theta[0], Xs[0].to(dev, dtype))
+    tol = 1e-12 if f64 else 1e-4
+    assert (mean1 - mean[0]).abs().max() <= tol * max(1.0, float(mean1.abs().max()))
+    assert (_lower(cov1, m) - _lower(cov[0], m)).abs().max() <= tol * float(_lower(cov1, m).abs().max())
+
+
 @pytest.mark.parametrize("model,d,n,m", [("loadest", 3, 300, 130), ("rating", 2, 200, 300), ("loadest", 3, 400, 700)])
 def test_posterior_factor_reproduces_the_covariance(model, d, n, m, gpu_device):
     dev = gpu_device
