@@ -18,6 +18,7 @@
 #include <mutex>
 #include "dgp_diag.h"
 #include "dgp_gemm.h"
+#include "dgp_gemm_dma.h"
 #include "dgp_internal.h"
 
 namespace dgp {
@@ -62,29 +63,28 @@ __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T
 // (bulk trailing update; nk = 2 halves the passes over the trailing matrix: 53.6 vs 44.5 TFLOP/s in isolation).
 // How C joins the accumulators differs by precision: trailing_begin / trailing_end below.
 //
-// All tiles cost the same and the GPU holds 512 of these workgroups at a time, so a launch of t tiles runs in
-// ceil(t / 512) rounds and its last round is on average half empty.  The first `nfull` tiles (whole rounds) are
+// All tiles cost the same and the GPU holds 512 (fp64: 768) of these workgroups at a time, so a launch of t tiles runs in
+// ceil(t / slots) rounds and its last round is on average half empty.  The first `nfull` tiles (whole rounds) are
 // done as 128 x 128 tiles; the rest is cut into `split` pieces each (2: 64 x 128 halves, 4: 64 x 64 quarters),
 // which fills the last round at a fraction of its time (SyrkShape picks the cheapest cut).
 template <typename T, int BM, int BN>
 __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int nk, long row0, long col0,
                                           T* __restrict__ smem) {
-  using G = TileGemm<T, true, true, BM, BN>;
+  using K = TileCore<T, true, true, BM, BN, (BM == 128 && BN == 128) ? Prefetch<T>::SYRK : 1>;
+  using G = typename K::G;
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
   typename G::acc_t keep[G::MI][G::NI];
   trailing_begin<T, G>(acc, keep, C, ld);
-  G::template run<(BM == 128 && BN == 128) ? Prefetch<T>::SYRK : 1>(A + row0 * ld + (long)k * NB, ld,
-                                                                   A + col0 * ld + (long)k * NB, ld, nk * (NB / 16),
-                                                                   smem, acc);
+  K::run(A + row0 * ld + (long)k * NB, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc);
   trailing_end<T, G>(acc, keep, C, ld);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg, int nfull,
-                                                      int split, long bs) {
+__global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg, int nfull,
+                                                                                   int split, long bs) {
   A = site(A, bs);
-  __shared__ T smem[TileGemm<T, true, true>::SMEM_ELEMS];
+  __shared__ T smem[TileCore<T, true, true>::SMEM_ELEMS];
   const int b = (int)blockIdx.x;
   int bi, bj;
   if (b < nfull) {
@@ -104,6 +104,12 @@ __global__ __launch_bounds__(256, 2) void syrk_kernel(T* __restrict__ A, long ld
   }
 }
 
+// workgroups of the bulk update the GPU holds at a time: 256 CUs x the tile core's occupancy
+template <typename T>
+static int syrk_slots() {
+  static const int v = getenv("DGP_SYRK_SLOTS") ? atoi(getenv("DGP_SYRK_SLOTS")) : 512;
+  return v;
+}
 // grid shape of one bulk launch: whole rounds of full tiles + the remainder cut into `split` pieces
 struct SyrkShape {
   int nfull, split;
@@ -217,7 +223,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, Bz), 256, 0, s>>>(A, Tinv, N, k, bt.ws);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
         {
-          const SyrkShape sh((int)tri(nbk - k - 1), 512 / bt.B);
+          const SyrkShape sh((int)tri(nbk - k - 1), syrk_slots<T>() / bt.B);
           syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s>>>(A, N, k, 1, k + 1, sh.nfull, sh.split, bt.ws);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s);
@@ -261,7 +267,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         hipStreamWaitEvent(s2, P[q - 1], 0);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
         {
-          const SyrkShape sh((int)tri(nbk - k0 - G), 512 / bt.B);
+          const SyrkShape sh((int)tri(nbk - k0 - G), syrk_slots<T>() / bt.B);
           syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s2>>>(A, N, k0 - G, G, k0 + G, sh.nfull, sh.split, bt.ws);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
@@ -549,7 +555,7 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
     if (kfirst < 0) kfirst = k - 1;
     hipStreamWaitEvent(s2, ER[k], 0);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
-    const SyrkShape sh((int)tri(nbk - k - 3), 512);
+    const SyrkShape sh((int)tri(nbk - k - 3), syrk_slots<T>());
     syrk_kernel<T><<<dim3(sh.grid, 1, 1), 256, 0, s2>>>(A, N, kfirst, nk, k + 3, sh.nfull, sh.split, 0);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
     flop += (double)nk * tile_flop * tri(nbk - k - 3);
@@ -654,10 +660,11 @@ int potrf_group(T* A, long ld, int nbk, T* Tinv, T* logdet, int* info, int k0, i
 //   T[i,j] = - sum_{c=mid}^{i} T[i,c] W[c,j]
 // BT = 128 for the large levels; the small levels (few tiles, short k) use 64x64 tiles so that four
 // times as many workgroups share the work.
-template <typename T, int STEP, int BT>
+template <typename T, int STEP, int BT, bool DMA = true>
 __device__ __forceinline__ void trtri_tile(const T* __restrict__ L, T* __restrict__ Tm, T* __restrict__ W, long ld,
                                            int m, int lo, int mid, int hi, int tile, T* __restrict__ smem) {
-  using G = TileGemm<T, true, false, BT, BT>;
+  using K = TileCore<T, true, false, BT, BT, Prefetch<T>::TRTRI, DMA>;
+  using G = typename K::G;
   constexpr int KT = BT / 16;  // k-tiles per tile of the reduction dimension
   // A group that the matrix edge cuts off has R = hi - mid < m tile rows: its R m tiles are the FIRST tile indices, so
   // that they are dealt over all XCDs (workgroup ids go round-robin over the 8 XCDs: with the full groups' i = mid + tile % m
@@ -671,13 +678,11 @@ __device__ __forceinline__ void trtri_tile(const T* __restrict__ L, T* __restric
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
   if (STEP == 0) {
-    G::template run<Prefetch<T>::TRTRI>(L + (long)i * BT * ld + (long)j * BT, ld, Tm + (long)j * BT * ld + (long)j * BT, ld,
-                                        (mid - j) * KT, smem, acc);
+    K::run(L + (long)i * BT * ld + (long)j * BT, Tm + (long)j * BT * ld + (long)j * BT, ld, (mid - j) * KT, smem, acc);
     T* out = W + (long)i * BT * ld + (long)j * BT;
     G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
   } else {
-    G::template run<Prefetch<T>::TRTRI>(Tm + (long)i * BT * ld + (long)mid * BT, ld, W + (long)mid * BT * ld + (long)j * BT,
-                                        ld, (i - mid + 1) * KT, smem, acc);
+    K::run(Tm + (long)i * BT * ld + (long)mid * BT, W + (long)mid * BT * ld + (long)j * BT, ld, (i - mid + 1) * KT, smem, acc);
     T* out = Tm + (long)i * BT * ld + (long)j * BT;
     G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = -v; });
   }
@@ -690,19 +695,22 @@ __device__ __forceinline__ void trtri_tile(const T* __restrict__ L, T* __restric
 // latency-critical chain kernels -- co-resident GEMM waves slow the diagonal-block kernel 2-5x.  Correctness does
 // not depend on where workgroups land: a reserved-CU workgroup only leaves once some other workgroup has
 // announced (ctr[1]) that it will drain the queue; until then it works like any other.
+// (the queue-driven launches keep the register-staged core at two workgroups per CU: they share the GPU with the panel chain,
+// whose kernels -- 228 registers, 97-110 KB of LDS -- only fit a CU that holds at most one GEMM workgroup; with three
+// 168-register workgroups per CU they wait for two to drain instead of one.  n = 8192, one site: fit step 12.4 ms with
+// the direct-to-LDS core here, 11.9 with the register-staged one)
 template <typename T, int STEP, int BT, bool QUEUE>
-__global__ __launch_bounds__(256, 2) void trtri_level_kernel(const T* __restrict__ L, T* __restrict__ Tm,
+__global__ __launch_bounds__(256, (TileCore<T, true, false, BT, BT, 1, !QUEUE>::OCC)) void trtri_level_kernel(const T* __restrict__ L, T* __restrict__ Tm,
                                                              T* __restrict__ W, long ld, int m, int ntile, int g0,
                                                              int ngroups, int* __restrict__ ctr,
                                                              const unsigned char* __restrict__ resv, long bs) {
-  using G = TileGemm<T, true, false, BT, BT>;
-  __shared__ T smem[G::SMEM_ELEMS];
+  __shared__ T smem[TileCore<T, true, false, BT, BT, 1, !QUEUE>::SMEM_ELEMS];
   if (!QUEUE) {
     L = site(L, bs);  // the queue-driven early launches are single-site only
     Tm = site(Tm, bs);
     W = site(W, bs);
     const int lo = 2 * m * (g0 + (int)blockIdx.y), mid = lo + m, hi = min(lo + 2 * m, ntile);
-    trtri_tile<T, STEP, BT>(L, Tm, W, ld, m, lo, mid, hi, (int)blockIdx.x, smem);
+    trtri_tile<T, STEP, BT, true>(L, Tm, W, ld, m, lo, mid, hi, (int)blockIdx.x, smem);
   } else {
     __shared__ int next_item;
     const int nitems = m * m * ngroups;
@@ -722,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void trtri_level_kernel(const T* __restrict
       if (it >= nitems) return;  // every workgroup gets here once the queue is empty
       const int g = it % ngroups, tile = it / ngroups;  // tile-major: the long-k tiles of every group first
       const int lo = 2 * m * (g0 + g), mid = lo + m, hi = min(lo + 2 * m, ntile);
-      trtri_tile<T, STEP, BT>(L, Tm, W, ld, m, lo, mid, hi, tile, smem);
+      trtri_tile<T, STEP, BT, false>(L, Tm, W, ld, m, lo, mid, hi, tile, smem);
     }
   }
 }
@@ -874,18 +882,19 @@ int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long
 // ------------------------------------------------------------------------------------------
 // S[i,j] = sum_{c >= i} T[c,i]^T T[c,j]   (i >= j): K^^-1 = L^-T L^-1
 template <typename T>
-__global__ __launch_bounds__(256, 2) void lauum_kernel(const T* __restrict__ Tm, T* __restrict__ S, long ld, int nbk,
-                                                       long bs) {
+__global__ __launch_bounds__(256, (TileCore<T, false, false>::OCC)) void lauum_kernel(const T* __restrict__ Tm, T* __restrict__ S, long ld,
+                                                                                      int nbk, long bs) {
   Tm = site(Tm, bs);
   S = site(S, bs);
-  using G = TileGemm<T, false, false>;
-  __shared__ T smem[G::SMEM_ELEMS];
+  using K = TileCore<T, false, false, 128, 128, Prefetch<T>::LAUUM>;
+  using G = typename K::G;
+  __shared__ T smem[K::SMEM_ELEMS];
   int bi, bj;
   tri_decode(blockIdx.x, bi, bj);  // ascending bi: the long-K tiles are dispatched first
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
   const T* base = Tm + (long)bi * NB * ld;
-  G::template run<Prefetch<T>::LAUUM>(base + (long)bi * NB, ld, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc);
+  K::run(base + (long)bi * NB, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc);
   T* out = S + (long)bi * NB * ld + (long)bj * NB;
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
 }
