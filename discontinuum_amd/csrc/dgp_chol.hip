@@ -75,9 +75,9 @@ __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
   typename G::acc_t keep[G::MI][G::NI];
-  trailing_begin<T, G>(acc, keep, C, ld);
-  K::run(A + row0 * ld + (long)k * NB, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc);
-  trailing_end<T, G>(acc, keep, C, ld);
+  trailing_begin<T, G, K::DMA>(acc, keep, C, ld);
+  K::run(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc);
+  trailing_end<T, G, K::DMA>(acc, keep, C, ld);
 }
 
 template <typename T>
@@ -678,11 +678,11 @@ __device__ __forceinline__ void trtri_tile(const T* __restrict__ L, T* __restric
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
   if (STEP == 0) {
-    K::run(L + (long)i * BT * ld + (long)j * BT, Tm + (long)j * BT * ld + (long)j * BT, ld, (mid - j) * KT, smem, acc);
+    K::run(L + (long)i * BT * ld + (long)j * BT, ld, Tm + (long)j * BT * ld + (long)j * BT, ld, (mid - j) * KT, smem, acc);
     T* out = W + (long)i * BT * ld + (long)j * BT;
     G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
   } else {
-    K::run(Tm + (long)i * BT * ld + (long)mid * BT, W + (long)mid * BT * ld + (long)j * BT, ld, (i - mid + 1) * KT, smem, acc);
+    K::run(Tm + (long)i * BT * ld + (long)mid * BT, ld, W + (long)mid * BT * ld + (long)j * BT, ld, (i - mid + 1) * KT, smem, acc);
     T* out = Tm + (long)i * BT * ld + (long)j * BT;
     G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = -v; });
   }
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(256, (TileCore<T, false, false>::OCC)) void lauum_k
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
   const T* base = Tm + (long)bi * NB * ld;
-  K::run(base + (long)bi * NB, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc);
+  K::run(base + (long)bi * NB, ld, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc);
   T* out = S + (long)bi * NB * ld + (long)bj * NB;
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
 }
@@ -1116,17 +1116,18 @@ int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s, 
 // prediction: V = T Ks (N x M, Ks = K(X, X*) padded to M % 128 == 0), var_j = kss_j - sum_i V_ij^2,
 // mean_j = sum_i Ks_ij alpha_i      (src/discontinuum/engines/gpytorch.py:621-624)
 template <typename T>
-__global__ __launch_bounds__(256, 2) void predict_v_kernel(const T* __restrict__ Tm, long N, const T* __restrict__ Ks,
+__global__ __launch_bounds__(256, (TileCore<T, true, false>::OCC)) void predict_v_kernel(const T* __restrict__ Tm, long N, const T* __restrict__ Ks,
                                                         long M, T* __restrict__ V, long bs, long wbs) {
   Tm = site(Tm, bs);  // batched plans: blockIdx.z = site; Ks, V in the caller's work area (site stride wbs)
   Ks = site(Ks, wbs);
   V = site(V, wbs);
-  using G = TileGemm<T, true, false>;
-  __shared__ T smem[G::SMEM_ELEMS];
+  using K = TileCore<T, true, false>;
+  using G = typename K::G;
+  __shared__ T smem[K::SMEM_ELEMS];
   const int bi = gridDim.y - 1 - blockIdx.y, bj = blockIdx.x;  // longest row blocks first
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
-  G::run(Tm + (long)bi * NB * N, N, Ks + (long)bj * NB, M, (bi + 1) * (NB / 16), smem, acc);
+  K::run(Tm + (long)bi * NB * N, N, Ks + (long)bj * NB, M, (bi + 1) * (NB / 16), smem, acc);
   T* out = V + (long)bi * NB * M + (long)bj * NB;
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * M + c] = v; });
 }
@@ -1192,9 +1193,10 @@ int predict_var(const T* Tm, long N, const T* Ks, long M, T* V, const T* alpha, 
 
 // cov[i,j] = Kss[i,j] - sum_k V[k,i] V[k,j]  (i >= j tiles), k over all N rows of V (N x M)
 template <typename T>
-__global__ __launch_bounds__(256, 2) void posterior_cov_kernel(const T* __restrict__ V, long N, long M, T* __restrict__ cov, long wbs) {
-  using G = TileGemm<T, false, false>;
-  __shared__ T smem[G::SMEM_ELEMS];
+__global__ __launch_bounds__(256, (TileCore<T, false, false>::OCC)) void posterior_cov_kernel(const T* __restrict__ V, long N, long M, T* __restrict__ cov, long wbs) {
+  using K = TileCore<T, false, false>;
+  using G = typename K::G;
+  __shared__ T smem[K::SMEM_ELEMS];
   V = site(V, wbs);  // batched plans: V in the caller's work area, cov [batch][M][M]
   cov = site(cov, M * M);
   int bi, bj;
@@ -1202,9 +1204,9 @@ __global__ __launch_bounds__(256, 2) void posterior_cov_kernel(const T* __restri
   typename G::acc_t acc[G::MI][G::NI];
   T* C = cov + (long)bi * NB * M + (long)bj * NB;
   typename G::acc_t keep[G::MI][G::NI];
-  trailing_begin<T, G>(acc, keep, C, M);
-  G::run(V + (long)bi * NB, M, V + (long)bj * NB, M, (int)(N / 16), smem, acc);
-  trailing_end<T, G>(acc, keep, C, M);
+  trailing_begin<T, G, K::DMA>(acc, keep, C, M);
+  K::run(V + (long)bi * NB, M, V + (long)bj * NB, M, (int)(N / 16), smem, acc);
+  trailing_end<T, G, K::DMA>(acc, keep, C, M);
 }
 
 template <typename T>
@@ -1222,15 +1224,16 @@ int posterior_cov(const T* V, long N, long M, T* cov, hipStream_t s, int B, long
 // stops at its diagonal block (the factorisation leaves zeros above the diagonal inside it).  Loads need no bounds:
 // L is M x M with the identity pad, Z is M x Q with Q % 128 == 0; only the stores are clipped to ndraw x m.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void sample_draws_kernel(const T* __restrict__ L, long ld, const T* __restrict__ Z,
+__global__ __launch_bounds__(256, (TileCore<T, false, true>::OCC)) void sample_draws_kernel(const T* __restrict__ L, long ld, const T* __restrict__ Z,
                                                               long ldz, const T* __restrict__ mean, int m, int ndraw,
                                                               T* __restrict__ out) {
-  using G = TileGemm<T, false, true>;
-  __shared__ T smem[G::SMEM_ELEMS];
+  using K = TileCore<T, false, true>;
+  using G = typename K::G;
+  __shared__ T smem[K::SMEM_ELEMS];
   const int bq = blockIdx.x, bj = gridDim.y - 1 - blockIdx.y;  // longest k-ranges first
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
-  G::run(Z + (long)bq * NB, ldz, L + (long)bj * NB * ld, ld, (bj + 1) * (NB / 16), smem, acc);
+  K::run(Z + (long)bq * NB, ldz, L + (long)bj * NB * ld, ld, (bj + 1) * (NB / 16), smem, acc);
   G::foreach (acc, [&](int r, int c, T& v) {
     const long q = (long)bq * NB + r, j = (long)bj * NB + c;
     if (q < ndraw && j < m) out[q * m + j] = v + (mean ? mean[j] : T(0));

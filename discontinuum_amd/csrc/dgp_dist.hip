@@ -30,6 +30,7 @@
 #include "../../include/dgp_hip.h"
 #include "dgp_common.h"
 #include "dgp_gemm.h"
+#include "dgp_gemm_dma.h"
 #include "dgp_internal.h"
 
 using namespace dgp;
@@ -96,10 +97,11 @@ struct SlabTiles {
   }
 };
 template <typename T>
-__global__ __launch_bounds__(256, 2) void slab_syrk_kernel(T* __restrict__ Aslab, long Cl, const T* __restrict__ P, int GW,
+__global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void slab_syrk_kernel(T* __restrict__ Aslab, long Cl, const T* __restrict__ P, int GW,
                                                            long c0, SlabTiles st, int cb, int ce) {
-  using G = TileGemm<T, true, true>;
-  __shared__ T smem[G::SMEM_ELEMS];
+  using K = TileCore<T, true, true>;
+  using G = typename K::G;
+  __shared__ T smem[K::SMEM_ELEMS];
   int lb, bi, bj;
   // plain order (a column's tiles follow each other, the hardware deals them round-robin over the XCDs, which then all read
   // the same column operand): the XCD-contiguous remap of dgp_common.h gives every XCD its own column region and measured
@@ -109,22 +111,23 @@ __global__ __launch_bounds__(256, 2) void slab_syrk_kernel(T* __restrict__ Aslab
   typename G::acc_t acc[G::MI][G::NI];
   T* C = Aslab + (long)bi * NB * Cl + (long)lb * NB;
   typename G::acc_t keep[G::MI][G::NI];
-  trailing_begin<T, G>(acc, keep, C, Cl);
-  G::run(P + ((long)bi * NB - c0) * GW, GW, P + ((long)bj * NB - c0) * GW, GW, GW / 16, smem, acc);
-  trailing_end<T, G>(acc, keep, C, Cl);
+  trailing_begin<T, G, K::DMA>(acc, keep, C, Cl);
+  K::run(P + ((long)bi * NB - c0) * GW, GW, P + ((long)bj * NB - c0) * GW, GW, GW / 16, smem, acc);
+  trailing_end<T, G, K::DMA>(acc, keep, C, Cl);
 }
 
 // T[G, H] = -Linv X[G, H] for the rank's groups H < g: row block i of the group needs X's row blocks <= i (Linv is
 // block lower triangular).  X is read from Sslab, T written to Tslab: no in-place hazard.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void slab_tconv_kernel(const T* __restrict__ Linv, int GW, const T* __restrict__ Sslab,
+__global__ __launch_bounds__(256, (TileCore<T, true, false>::OCC)) void slab_tconv_kernel(const T* __restrict__ Linv, int GW, const T* __restrict__ Sslab,
                                                             T* __restrict__ Tslab, long Cl, long c0) {
-  using G = TileGemm<T, true, false>;
-  __shared__ T smem[G::SMEM_ELEMS];
+  using K = TileCore<T, true, false>;
+  using G = typename K::G;
+  __shared__ T smem[K::SMEM_ELEMS];
   const int i = (int)blockIdx.x, lb = (int)blockIdx.y;
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
-  G::run(Linv + (long)i * NB * GW, GW, Sslab + c0 * Cl + (long)lb * NB, Cl, (i + 1) * (NB / 16), smem, acc);
+  K::run(Linv + (long)i * NB * GW, GW, Sslab + c0 * Cl + (long)lb * NB, Cl, (i + 1) * (NB / 16), smem, acc);
   T* out = Tslab + (c0 + (long)i * NB) * Cl + (long)lb * NB;
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * Cl + c] = -v; });
 }
@@ -132,10 +135,11 @@ __global__ __launch_bounds__(256, 2) void slab_tconv_kernel(const T* __restrict_
 // X[i, lb] (+)= P[i, :] T[G, lb] for the rows below the group.  Columns of the group itself (the owner's local blocks
 // own0 .. own0 + W - 1) start their sums here: column h of the group only has T[G, h] from its own diagonal block down.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void slab_xacc_kernel(const T* __restrict__ P, int GW, long c0, const T* __restrict__ Tslab,
+__global__ __launch_bounds__(256, (TileCore<T, true, false>::OCC)) void slab_xacc_kernel(const T* __restrict__ P, int GW, long c0, const T* __restrict__ Tslab,
                                                            T* __restrict__ Sslab, long Cl, int own0, int W) {
-  using G = TileGemm<T, true, false>;
-  __shared__ T smem[G::SMEM_ELEMS];
+  using K = TileCore<T, true, false>;
+  using G = typename K::G;
+  __shared__ T smem[K::SMEM_ELEMS];
   const int bi = (int)((c0 + GW) / NB) + (int)blockIdx.x, lb = (int)blockIdx.y;
   const int h = lb - own0;
   const bool fresh = own0 >= 0 && h >= 0 && h < W;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void slab_xacc_kernel(const T* __restrict__
   const bool from_zero = fresh || sizeof(T) == 4;
   if (from_zero) G::zero(acc);
   else G::foreach (acc, [&](int r, int c, T& v) { v = X[(long)r * Cl + c]; });
-  G::run(P + ((long)bi * NB - c0) * GW + koff, GW, Tslab + (c0 + koff) * Cl + (long)lb * NB, Cl, (int)((GW - koff) / 16), smem, acc);
+  K::run(P + ((long)bi * NB - c0) * GW + koff, GW, Tslab + (c0 + koff) * Cl + (long)lb * NB, Cl, (int)((GW - koff) / 16), smem, acc);
   if (from_zero && !fresh) G::foreach (acc, [&](int r, int c, T& v) { X[(long)r * Cl + c] += v; });
   else G::foreach (acc, [&](int r, int c, T& v) { X[(long)r * Cl + c] = v; });
 }
@@ -155,10 +159,11 @@ __global__ __launch_bounds__(256, 2) void slab_xacc_kernel(const T* __restrict__
 // Pass 2: S[bj, bi] = sum_{c >= bi} T[c, bj]^T T[c, bi] for the rank's block columns bi >= bj, bj in the broadcast group
 // (Q row 0 = global row c0).  BT = 64 when the step has too few 128-tiles to fill the GPU.
 template <typename T, int BT>
-__global__ __launch_bounds__(256, 2) void slab_ttt_kernel(const T* __restrict__ Q, int GW, long c0, const T* __restrict__ Tslab,
+__global__ __launch_bounds__(256, (TileCore<T, false, false, BT, BT>::OCC)) void slab_ttt_kernel(const T* __restrict__ Q, int GW, long c0, const T* __restrict__ Tslab,
                                                           T* __restrict__ Sslab, long Cl, long N, SlabMap sm, int lb0) {
-  using G = TileGemm<T, false, false, BT, BT>;
-  __shared__ T smem[G::SMEM_ELEMS];
+  using K = TileCore<T, false, false, BT, BT>;
+  using G = typename K::G;
+  __shared__ T smem[K::SMEM_ELEMS];
   constexpr int PER = NB / BT;  // sub-tiles per 128-block and dimension
   const int jq = (int)blockIdx.x, lq = (int)blockIdx.y;  // in units of BT
   const int lb = lb0 + lq / PER, bi = sm.gblock(lb);
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void slab_ttt_kernel(const T* __restrict__ 
   const long k0 = (long)bi * NB;                                           // T[:, bi] starts at its diagonal block
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
-  G::run(Q + (k0 - c0) * GW + (long)jq * BT, GW, Tslab + k0 * Cl + (long)lb * NB + (long)(lq % PER) * BT, Cl,
+  K::run(Q + (k0 - c0) * GW + (long)jq * BT, GW, Tslab + k0 * Cl + (long)lb * NB + (long)(lq % PER) * BT, Cl,
          (int)((N - k0) / 16), smem, acc);
   T* out = Sslab + col_j * Cl + (long)lb * NB + (long)(lq % PER) * BT;
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * Cl + c] = v; });

@@ -1,27 +1,31 @@
-// dgp_gemm_dma.h -- the fp64 128 x 128 tile-GEMM core with operands moved global -> LDS directly, THREE workgroups per CU.
+// dgp_gemm_dma.h -- the 128 x 128 tile-GEMM core with operands moved global -> LDS directly, THREE workgroups per CU.
 //
-// Same contract as TileGemm<double, A_KC, B_KC, 128, 128> (dgp_gemm.h): 256 threads = 4 waves (2 x 2) accumulate
+// Same contract as TileGemm<T, A_KC, B_KC, 128, 128> (dgp_gemm.h): 256 threads = 4 waves (2 x 2) accumulate
 //     acc[i][j] += sum_k opA(i, k) * opB(j, k),   KC: op(i, k) = p[i ld + k],   IC: op(i, k) = p[k ld + i]
 // with the SAME accumulator layout and the SAME order of the k-sum: its results are bitwise those of TileGemm.
 //
-// Why a second core.  The register-staged core (global -> VGPR -> LDS, two barriers per k-tile) needs 208-246 registers, so two
-// waves share a SIMD, and it runs at 68-70 TFLOP/s alone whatever is done to its barriers or its staging (scripts/gemm_wave.hip:
-// wave-private staging, software pipelining and direct-to-LDS loads all end at 70 with two waves per SIMD).  The same MFMA loop
-// reaches 76-77 of the 78.6 TFLOP/s peak as soon as a THIRD wave fits every SIMD: 512 / 3 -> at most 168 registers per lane and
-// 53 KB of LDS per workgroup.  The accumulators alone are 128 registers, which leaves no room for staging registers -- hence:
+// Why a second core.  The register-staged core (global -> VGPR -> LDS, two barriers per k-tile) needs 208-246 registers in
+// fp64, so two waves share a SIMD, and it runs at 68-70 TFLOP/s alone whatever is done to its barriers or its staging
+// (scripts/gemm_wave.hip: wave-private staging, software pipelining and direct-to-LDS loads all end at 70 with two waves per
+// SIMD).  The same MFMA loop reaches 76-77 of the 78.6 TFLOP/s peak as soon as a THIRD wave fits every SIMD: 512 / 3 -> at most
+// 168 registers per lane and 53 KB of LDS per workgroup.  The fp64 accumulators alone are 128 registers, which leaves no room
+// for staging registers -- hence:
 //   * global_load_lds_dwordx4: the operands never pass through registers, no ds_write is issued;
-//   * ring of 3 CHUNKS of 8 k's (A 128 x 8 + B 128 x 8 doubles = 16 KB a chunk, 48 KB a workgroup); every wave issues a quarter
-//     of a chunk (2 + 2 instructions of 1 KB), ONE barrier per chunk: it publishes chunk c + 1 and frees the slot of chunk c, into
-//     which chunk c + 3 is issued at once -- two chunk-times (64 MFMAs per wave) of prefetch distance;
+//   * ring of 3 CHUNKS of 64 bytes of k (8 doubles / 16 floats; A 128 rows + B 128 rows = 16 KB a chunk, 48 KB a workgroup); every
+//     wave issues a quarter of a chunk (2 + 2 instructions of 1 KB), ONE barrier per chunk: it publishes chunk c + 1 and frees the
+//     slot of chunk c, into which chunk c + 3 is issued at once -- two chunk-times (64 MFMAs per wave) of prefetch distance;
 //   * a load instruction writes its 64 x 16 bytes to LDS in lane order, so the LDS image is chosen through WHICH address a lane
-//     fetches:  IC operand: a whole k-row of the tile (128 doubles) per instruction, lane l fetching column 2 l ^ 16 (k & 3) --
-//     the XOR spreads the four k's of a fragment read over the banks and only permutes 128-byte groups inside the 1 KB row;
-//     KC operand: 16 rows x 64 bytes per instruction (lane l: row l & 15, k-pair l >> 4), image [16-row group][k-pair][row][2];
-//     every fragment read (ds_read_b64, 64 lanes) is bank-conflict free in both;
+//     fetches.  IC operand: whole k-rows of the tile (fp64: one row of 128 doubles per instruction, fp32: two rows of 128 floats),
+//     lane l fetching column (its 16-byte unit) ^ 16 (k & 3) -- the XOR spreads the four k's of a fragment read over the banks and
+//     only permutes 64- / 128-byte groups inside the row.  KC operand: 16 rows x 64 bytes per instruction (lane l: row l & 15,
+//     unit l >> 4), image [16-row group][unit][row][16 bytes].  Every fragment read (ds_read_b64 / _b32, 64 lanes) is bank-conflict
+//     free in all four cases;
 //   * base pointers stay in scalar registers (global_load saddr form, written as assembly: the compiler otherwise turns them
 //     into 64-bit per-lane induction variables and spills).
-// Measured alone (scripts/gemm_wave.hip, n = 8192, IC/IC): K = 8192 76.7, K = 512 67.5 TFLOP/s (register-staged core 68.2 / 55.9).
-// Roofline: MFMA (v_mfma_f64_16x16x4_f64, 64 cycles per 2048 flop per SIMD).
+// fp32 has half the accumulator registers and would fit the old core at three waves too, but gains the same way (lauum 131 ->
+// 142-147 TFLOP/s in situ); trailing updates read C in the epilogue there (dgp_gemm.h::trailing_begin, LATE).
+// Measured alone (scripts/gemm_wave.hip, fp64 n = 8192, IC/IC): K = 8192 76.7, K = 512 67.5 TFLOP/s (register-staged core 68.2 /
+// 55.9).  Roofline: MFMA (v_mfma_f64_16x16x4_f64: 64 cycles per 2048 flop per SIMD; v_mfma_f32_16x16x4_f32: 32).
 #pragma once
 #include "dgp_gemm.h"
 
@@ -29,13 +33,17 @@ namespace dgp {
 
 typedef __attribute__((address_space(3))) void* dgp_lds_ptr;
 
-template <bool A_KC, bool B_KC>
-struct DmaGemm64 {
+template <typename T, bool A_KC, bool B_KC>
+struct DmaGemm {
+  static constexpr bool F64 = sizeof(T) == 8;
+  static constexpr int EPU = 16 / (int)sizeof(T);    // elements per 16-byte unit (what one lane fetches)
+  static constexpr int KCH = F64 ? 8 : 16;           // k's per chunk: 64 bytes of a k-contiguous row
+  static constexpr int KS = KCH / 4;                 // MFMA k-steps per chunk
   static constexpr int SLOTS = 3;
-  static constexpr int AREA = 1024;               // doubles of one operand's chunk (128 x 8)
-  static constexpr int SLOT_ELEMS = 2 * AREA;     // A then B
+  static constexpr int AREA = 128 * KCH;             // elements of one operand's chunk (8 KB)
+  static constexpr int SLOT_ELEMS = 2 * AREA;        // A then B
   static constexpr int SMEM_ELEMS = SLOTS * SLOT_ELEMS;  // 48 KB
-  using acc_t = dgp_d4;
+  using acc_t = typename Mfma<T>::acc_t;
 
   template <int N>
   static __device__ __forceinline__ void wait_vm() {  // s_waitcnt vmcnt(N) alone
@@ -46,48 +54,57 @@ struct DmaGemm64 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory", "m0");
   }
 
-  // One operand: what wave w fetches of a chunk (two instructions: bases p0 / p1, the same lane offset) and where it lands.
+  // One operand: what wave w fetches of a chunk (two instructions of 1 KB: bases p0 / p1, the same lane offset) and where it lands.
+  //   KC (either precision): instruction = 16 rows x 64 bytes, lane l: row l & 15, unit l >> 4; wave w: rows 32 w .. 32 w + 31.
+  //   IC fp64: instruction = one k-row of 128 doubles; wave w: k-rows w and w + 4 (the same swizzle).
+  //   IC fp32: instruction = two k-rows of 128 floats (lane l: row l >> 5); wave w: k-rows 2 w, 2 w + 1 and 2 w + 8, 2 w + 9.
   template <bool KC>
   struct Op {
     static __device__ __forceinline__ unsigned voff(int lane, int w, long ld) {
-      if (KC) return (unsigned)(((long)(lane & 15) * ld + 2 * (lane >> 4)) * 8);
-      return (unsigned)(((2 * lane) ^ (16 * (w & 3))) * 8);  // k-rows w and w + 4 share the swizzle
+      if (KC) return (unsigned)((long)(lane & 15) * ld * (long)sizeof(T) + 16 * (lane >> 4));
+      if (F64) return (unsigned)(((2 * lane) ^ (16 * (w & 3))) * 8);
+      const int k = lane >> 5;
+      return (unsigned)(((long)k * ld + ((4 * (lane & 31)) ^ (16 * ((2 * w + k) & 3)))) * 4);
     }
-    static __device__ __forceinline__ const char* base0(const double* p, int w, long ld) {
-      return (const char*)(KC ? p + (long)(32 * w) * ld : p + (long)w * ld);
+    static __device__ __forceinline__ const char* base0(const T* p, int w, long ld) {
+      return (const char*)(KC ? p + (long)(32 * w) * ld : p + (long)((F64 ? 1 : 2) * w) * ld);
     }
-    static __device__ __forceinline__ long second(long ld) { return (KC ? 16 * ld : 4 * ld) * 8; }  // base1 - base0, bytes
-    static __device__ __forceinline__ long step(long ld) { return KC ? 64 : 8 * ld * 8; }           // bytes per chunk
+    static __device__ __forceinline__ long second(long ld) { return (KC ? 16 * ld : (F64 ? 4 : 8) * ld) * (long)sizeof(T); }  // base1 - base0
+    static __device__ __forceinline__ long step(long ld) { return KC ? 64 : KCH * ld * (long)sizeof(T); }                   // bytes per chunk
     static constexpr unsigned LDS0 = KC ? 2048 : 1024;  // x w: LDS byte offset of the wave's first instruction in the operand's area
     static constexpr unsigned LDS1 = KC ? 1024 : 4096;  // of the second one, relative to the first
-    // fragment address (double index inside the operand's area) of rows wh + 16 mi + (lane & 15), k = 4 ks + (lane >> 4):
-    //   KC: q[0] + 128 mi + 64 ks        IC: q[mi] + 512 ks
+    // fragment address (element index inside the operand's area) of rows wh + 16 mi + (lane & 15), k = 4 ks + (lane >> 4):
+    //   KC: q[0] + MI_STRIDE mi + 64 ks        IC: q[mi] + 512 ks
+    static constexpr int MI_STRIDE = 16 * 4 * EPU;  // a 16-row group is 4 units x 16 rows x EPU elements
     static __device__ __forceinline__ void frag_base(int lane, int wh, int (&q)[4]) {
       const int fk = lane >> 4, r = lane & 15;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) q[mi] = KC ? 8 * wh + 32 * (fk >> 1) + 2 * r + (fk & 1) : fk * 128 + wh + ((mi ^ fk) & 3) * 16 + r;
+      for (int mi = 0; mi < 4; ++mi) {
+        if (KC) q[mi] = F64 ? 8 * wh + 32 * (fk >> 1) + 2 * r + (fk & 1) : 16 * wh + 4 * r + fk;
+        else q[mi] = fk * 128 + wh + ((mi ^ fk) & 3) * 16 + r;
+      }
     }
-    static __device__ __forceinline__ double frag(const double* __restrict__ area, const int (&q)[4], int mi, int ks) {
-      return KC ? area[q[0] + 128 * mi + 64 * ks] : area[q[mi] + 512 * ks];
+    static __device__ __forceinline__ T frag(const T* __restrict__ area, const int (&q)[4], int mi, int ks) {
+      return KC ? area[q[0] + MI_STRIDE * mi + 64 * ks] : area[q[mi] + 512 * ks];
     }
   };
   using OA = Op<A_KC>;
   using OB = Op<B_KC>;
 
-  // A, B: (row 0, k 0) of the operand tiles, both with leading dimension ld; ktiles counts k in units of 16 (>= 1).
-  // acc comes in initialised (zero, or -C for a trailing update).  All 256 threads must call it together.
-  static __device__ __forceinline__ void run(const double* __restrict__ A, const double* __restrict__ B, long ld, int ktiles,
-                                             double* __restrict__ smem, acc_t (&acc)[4][4]) {
+  // A, B: (row 0, k 0) of the operand tiles with leading dimensions lda, ldb; ktiles counts k in units of 16, at least 4 (every
+  // caller's k-range is a multiple of 64).  acc comes in initialised (zero, or -C for a trailing update).  All 256 threads call it together.
+  static __device__ __forceinline__ void run(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int ktiles,
+                                             T* __restrict__ smem, acc_t (&acc)[4][4]) {
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const unsigned va = OA::voff(lane, w, ld), vb = OB::voff(lane, w, ld);
-    const char* a = OA::base0(A, w, ld);
-    const char* b = OB::base0(B, w, ld);
-    const long a2 = OA::second(ld), b2 = OB::second(ld), sa = OA::step(ld), sb = OB::step(ld);
+    const unsigned va = OA::voff(lane, w, lda), vb = OB::voff(lane, w, ldb);
+    const char* a = OA::base0(A, w, lda);
+    const char* b = OB::base0(B, w, ldb);
+    const long a2 = OA::second(lda), b2 = OB::second(ldb), sa = OA::step(lda), sb = OB::step(ldb);
     const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(dgp_lds_ptr)smem);
-    const unsigned la = lds + w * OA::LDS0, lb = lds + AREA * 8 + w * OB::LDS0;
+    const unsigned la = lds + w * OA::LDS0, lb = lds + AREA * (unsigned)sizeof(T) + w * OB::LDS0;
     auto issue = [&](int slot) {
-      const unsigned o = slot * (SLOT_ELEMS * 8);
+      const unsigned o = slot * (SLOT_ELEMS * (unsigned)sizeof(T));
       dma(va, a, la + o);
       dma(va, a + a2, la + o + OA::LDS1);
       dma(vb, b, lb + o);
@@ -98,9 +115,9 @@ struct DmaGemm64 {
     int qa[4], qb[4];
     OA::frag_base(lane, (w >> 1) * 64, qa);
     OB::frag_base(lane, (w & 1) * 64, qb);
-    double f[8];
+    T f[8];
     auto frags = [&](int slot, int ks) {
-      const double* d = smem + slot * SLOT_ELEMS;
+      const T* d = smem + slot * SLOT_ELEMS;
 #pragma unroll
       for (int i = 0; i < 4; ++i) f[i] = OA::frag(d, qa, i, ks), f[4 + i] = OB::frag(d + AREA, qb, i, ks);
     };
@@ -108,24 +125,28 @@ struct DmaGemm64 {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[mi], f[4 + ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Mfma<T>::mma(f[mi], f[4 + ni], acc[mi][ni]);
     };
-    const int C = ktiles * 2;  // chunks: even, at least 2
-    __syncthreads();           // an earlier use of the ring by this workgroup is over
+    auto chunk = [&](int slot) {  // the MFMAs of one chunk; its first fragments are already in registers
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        mma();
+        if (ks + 1 < KS) frags(slot, ks + 1);
+      }
+    };
+    const int C = ktiles * 16 / KCH;  // chunks, at least 4
+    __syncthreads();                  // an earlier use of the ring by this workgroup is over
     issue(0);
     issue(1);
-    if (C > 2) issue(2);
-    if (C > 2) wait_vm<8>();
-    else wait_vm<4>();
+    issue(2);
+    wait_vm<8>();
     __syncthreads();  // chunk 0 is complete
     frags(0, 0);
     int c0 = 0;
     for (; c0 + 2 * SLOTS <= C; c0 += SLOTS) {  // steady state, branch-free: every chunk of the round has a chunk three ahead
 #pragma unroll
       for (int u = 0; u < SLOTS; ++u) {
-        mma();
-        frags(u, 1);
-        mma();
+        chunk(u);
         wait_vm<4>();     // this wave's part of chunk c + 1 has landed (chunk c + 2 may be in flight)
         __syncthreads();  // ... everyone's has; and everyone has chunk c in registers or behind it
         issue(u);         // chunk c + 3 into the slot of chunk c
@@ -136,11 +157,7 @@ struct DmaGemm64 {
 #pragma unroll
       for (int u = 0; u < SLOTS; ++u) {
         const int c = c0 + u;
-        if (c < C) {
-          mma();
-          frags(u, 1);
-          mma();
-        }
+        if (c < C) chunk(u);
         wait_vm<0>();
         __syncthreads();
         if (c + 3 < C) issue(u);
@@ -150,19 +167,19 @@ struct DmaGemm64 {
   }
 };
 
-// Which core a kernel's tile uses: the direct-to-LDS one for fp64 128 x 128 tiles, the register-staged one otherwise.
+// Which core a kernel's tile uses: the direct-to-LDS one for 128 x 128 tiles, the register-staged one otherwise.
 // OCC is the kernel's __launch_bounds__ occupancy, SMEM_ELEMS its LDS array.
 template <typename T, bool A_KC, bool B_KC, int BM = 128, int BN = 128, int PF = 1, bool ALLOW_DMA = true>
 struct TileCore {
   using G = TileGemm<T, A_KC, B_KC, BM, BN>;
-  using D = DmaGemm64<A_KC, B_KC>;
-  static constexpr bool DMA = ALLOW_DMA && sizeof(T) == 8 && BM == 128 && BN == 128;
+  using D = DmaGemm<T, A_KC, B_KC>;
+  static constexpr bool DMA = ALLOW_DMA && BM == 128 && BN == 128;
   static constexpr int OCC = DMA ? 3 : 2;
   static constexpr int SMEM_ELEMS = DMA ? D::SMEM_ELEMS : G::SMEM_ELEMS;
-  static __device__ __forceinline__ void run(const T* __restrict__ A, const T* __restrict__ B, long ld, int ktiles, T* __restrict__ smem,
-                                             typename G::acc_t (&acc)[G::MI][G::NI]) {
-    if constexpr (DMA) D::run(A, B, ld, ktiles, smem, acc);
-    else G::template run<PF>(A, ld, B, ld, ktiles, smem, acc);
+  static __device__ __forceinline__ void run(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int ktiles,
+                                             T* __restrict__ smem, typename G::acc_t (&acc)[G::MI][G::NI]) {
+    if constexpr (DMA) D::run(A, lda, B, ldb, ktiles, smem, acc);
+    else G::template run<PF>(A, lda, B, ldb, ktiles, smem, acc);
   }
 };
 
