@@ -155,6 +155,18 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, lon
   trailing_end<T, G>(acc, keep, C, ld);
 }
 
+// the same columns in 128 x 128 tiles of the direct-to-LDS core, for batched plans: there the group's column update is
+// thousands of tiles and not latency-critical (the sites fill each other's gaps); bitwise the same sums
+template <typename T>
+__global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_col128_kernel(T* __restrict__ A, long ld, int k, int nk, int jcol,
+                                                                                          int nbk, int ncol, long bs) {
+  __shared__ T smem[TileCore<T, true, true>::SMEM_ELEMS];
+  A += (long)((int)blockIdx.z / ncol) * bs;
+  const int jc = jcol + (int)blockIdx.z % ncol;
+  if ((int)blockIdx.x >= nbk - jc) return;  // the later columns are shorter
+  syrk_tile<T, 128, 128>(A, ld, k, nk, (long)(jc + (int)blockIdx.x) * NB, (long)jc * NB, smem);
+}
+
 // launch the LDS-resident diagonal-block kernel (needs > 64 KB of dynamic LDS: opt in once per instantiation).
 // DGP_F32_DIAG64=1 factors the diagonal blocks of fp32 matrices with the MIXED-PRECISION instantiation (block promoted
 // to fp64 in LDS, dgp_diag.h).  Off by default -- measured over 18 matrices (profiles/r03_fp32_error_sources.txt): once
@@ -260,8 +272,11 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
     for (int q = 0; q < Qrun; ++q) {
       const int k0 = G * q, ncol = nbk - k0 < G ? nbk - k0 : G;
       if (q >= 2) hipStreamWaitEvent(s, U[q - 2], 0);  // bulk(q-2) exists whenever chain(q) does
-      if (q >= 1)
-        syrk_col_kernel<T><<<dim3(2 * (nbk - k0), 2, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
+      if (q >= 1) {
+        static const int col128 = getenv("DGP_COL128") ? atoi(getenv("DGP_COL128")) : 4;  // batch size from which the group's columns use 128-tiles
+        if (bt.B >= col128) syrk_col128_kernel<T><<<dim3(nbk - k0, 1, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
+        else syrk_col_kernel<T><<<dim3(2 * (nbk - k0), 2, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
+      }
       if (q >= 1 && k0 + G < nbk) {  // bulk(q-1): columns >= G(q+1) exist
         hipEventRecord(P[q - 1], s);
         hipStreamWaitEvent(s2, P[q - 1], 0);
@@ -820,7 +835,8 @@ static void trtri_level(const T* L, T* Tm, T* W, long N, long ld, int mblk, int 
     const int rows = nbk128 - (2 * mblk * g + mblk);
     tiles += (long)(rows < mblk ? (rows > 0 ? rows : 0) : mblk) * mblk;
   }
-  const bool small = tiles * bt.B < 1024;
+  static const long small_lim = getenv("DGP_TRTRI_SMALL") ? atol(getenv("DGP_TRTRI_SMALL")) : 1024;
+  const bool small = tiles * bt.B < small_lim;
   const int m = small ? 2 * mblk : mblk, ntile = (int)(N / (small ? 64 : 128));
   const bool queue = early != nullptr && early->pairs_left > 0 && m * m * ng > early->wg_cap;
   if (!queue) {

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <vector>
 #include "dgp_gemm.h"
+#include "dgp_gemm_dma.h"
 using namespace dgp;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -712,7 +713,73 @@ int run(const char* name, long n, int K) {
   return 0;
 }
 
+// ---- the PRODUCT's direct-to-LDS core (dgp_gemm_dma.h) against TileGemm, every operand combination, both precisions
+template <typename T, bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 3) void gemm_product_kernel(const T* A, const T* B, T* C, long n, int ktiles) {
+  using D = DmaGemm<T, AKC, BKC>;
+  using G = TileGemm<T, AKC, BKC, 128, 128>;
+  __shared__ T smem[D::SMEM_ELEMS];
+  const long bi = blockIdx.y, bj = blockIdx.x;
+  typename G::acc_t acc[4][4];
+  G::zero(acc);
+  const T* a = AKC ? A + bi * 128 * n : A + bi * 128;
+  const T* b = BKC ? B + bj * 128 * n : B + bj * 128;
+  D::run(a, n, b, n, ktiles, smem, acc);
+  T* out = C + bi * 128 * n + bj * 128;
+  G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * n + c] = v; });
+}
+
+template <typename T, bool AKC, bool BKC, int PF>
+int run_product(const char* name, long n) {
+  T *A, *B, *C, *C2;
+  CK(hipMalloc(&A, n * n * sizeof(T))); CK(hipMalloc(&B, n * n * sizeof(T))); CK(hipMalloc(&C, n * n * sizeof(T))); CK(hipMalloc(&C2, n * n * sizeof(T)));
+  std::vector<T> h(n * n);
+  for (long i = 0; i < n * n; ++i) h[i] = (T)((double)rand() / RAND_MAX - 0.5);
+  CK(hipMemcpy(A, h.data(), n * n * sizeof(T), hipMemcpyHostToDevice));
+  for (long i = 0; i < n * n; ++i) h[i] = (T)((double)rand() / RAND_MAX - 0.5);
+  CK(hipMemcpy(B, h.data(), n * n * sizeof(T), hipMemcpyHostToDevice));
+  dim3 grid(n / 128, n / 128);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<T> c1(n * n), c2(n * n);
+  const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 5;  // REPS=60: ~1 s of sustained load per measurement (power / clock steady state)
+  for (int K : {512, 1024, 8192}) {
+    float ms_ref, ms_d;
+    gemm_ref_kernel<T, AKC, BKC, PF><<<grid, 256>>>(A, B, C, n, K / 16);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) gemm_ref_kernel<T, AKC, BKC, PF><<<grid, 256>>>(A, B, C, n, K / 16);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms_ref, e0, e1)); ms_ref /= reps;
+    gemm_product_kernel<T, AKC, BKC><<<grid, 256>>>(A, B, C2, n, K / 16);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) gemm_product_kernel<T, AKC, BKC><<<grid, 256>>>(A, B, C2, n, K / 16);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms_d, e0, e1)); ms_d /= reps;
+    CK(hipMemcpy(c1.data(), C, n * n * sizeof(T), hipMemcpyDeviceToHost)); CK(hipMemcpy(c2.data(), C2, n * n * sizeof(T), hipMemcpyDeviceToHost));
+    double md = 0;
+    for (long i = 0; i < n * n; ++i) md = fmax(md, fabs((double)c1[i] - (double)c2[i]));
+    const double fl = 2.0 * n * n * K / 1e9;
+    printf("product core %-10s n %ld K %5d: TileGemm (PF %d) %.3f ms %6.1f TF | DmaGemm %.3f ms %6.1f TF | max |diff| %.3g\n", name, n, K, PF, ms_ref, fl / ms_ref, ms_d,
+           fl / ms_d, md);
+  }
+  CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(C2));
+  return 0;
+}
+
 int main() {
+  if (!getenv("EXPERIMENTS")) {  // default: the shipped core; EXPERIMENTS=1 runs the variants that led to it
+    run_product<double, false, false, 2>("f64 IC/IC", 8192);
+    if (getenv("ONLY_FIRST")) return 0;
+    run_product<double, true, false, 1>("f64 KC/IC", 8192);
+    run_product<double, true, true, 1>("f64 KC/KC", 8192);
+    run_product<double, false, true, 1>("f64 IC/KC", 8192);
+    run_product<float, false, false, 4>("f32 IC/IC", 8192);
+    run_product<float, true, false, 4>("f32 KC/IC", 8192);
+    run_product<float, true, true, 2>("f32 KC/KC", 8192);
+    run_product<float, false, true, 2>("f32 IC/KC", 8192);
+    return 0;
+  }
   {
     const long n = 8192;
     double *A, *B, *C;
