@@ -665,8 +665,10 @@ int parts(const double* A, const double* B, double* C, long n, int K) {
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
   long long clk[4];
   CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk)));
-  printf("parts: global loads %d, LDS stores %d, fragment reads %d: %.3f ms %.1f TF   (probe workgroup: %lld shader clocks in %.1f us = %.0f MHz)\n", LOADS, STORES, READS, ms,
-         2.0 * n * n * K / ms / 1e9, clk[0], clk[1] / 100.0, clk[0] / (clk[1] / 100.0));
+  int occ = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, parts_kernel<LOADS, STORES, READS>, 256, lds));
+  printf("parts: global loads %d, LDS stores %d, fragment reads %d: %.3f ms %.1f TF   (%d workgroups per CU; probe workgroup: %lld shader clocks in %.1f us = %.0f MHz)\n", LOADS, STORES, READS, ms,
+         2.0 * n * n * K / ms / 1e9, occ, clk[0], clk[1] / 100.0, clk[0] / (clk[1] / 100.0));
   return 0;
 }
 
@@ -802,9 +804,10 @@ int main() {
     CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
   }
   for (int K : {512, 8192}) {
-    run_dma<0>(8192, K);
-    run_dma<16>(8192, K);
-    run_dma<14>(8192, K);
+    run_dma<4>(8192, K);   // wave-private ring of 4 stages, two workgroups per CU
+    run_dma<0>(8192, K);   // wave-private ring of 3 stages, three workgroups per CU
+    run_dma<14>(8192, K);  // workgroup-shared ring of 4 stages, three per CU
+    run_dma<16>(8192, K);  // ... of 6 stages (spills)
   }
   if (getenv("ALL")) for (int K : {512, 8192}) {
     run_pipe<false, false>("f64 IC/IC", 8192, K);
