@@ -91,8 +91,8 @@ struct DmaGemm {
   using OA = Op<A_KC>;
   using OB = Op<B_KC>;
 
-  // A, B: (row 0, k 0) of the operand tiles with leading dimensions lda, ldb; ktiles counts k in units of 16, at least 4 (every
-  // caller's k-range is a multiple of 64).  acc comes in initialised (zero, or -C for a trailing update).  All 256 threads call it together.
+  // A, B: (row 0, k 0) of the operand tiles with leading dimensions lda, ldb; ktiles >= 1 counts k in units of 16 (every caller's
+  // k-range is a multiple of 128).  acc comes in initialised (zero, or -C for a trailing update).  All 256 threads call it together.
   static __device__ __forceinline__ void run(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int ktiles,
                                              T* __restrict__ smem, acc_t (&acc)[4][4]) {
     const int t = threadIdx.x, lane = t & 63;
@@ -134,12 +134,14 @@ struct DmaGemm {
         if (ks + 1 < KS) frags(slot, ks + 1);
       }
     };
-    const int C = ktiles * 16 / KCH;  // chunks, at least 4
+    const int C = ktiles * 16 / KCH;  // chunks (every caller has at least 8; any count >= 1 is handled)
     __syncthreads();                  // an earlier use of the ring by this workgroup is over
     issue(0);
-    issue(1);
-    issue(2);
-    wait_vm<8>();
+    if (C > 1) issue(1);
+    if (C > 2) issue(2);
+    if (C > 2) wait_vm<8>();
+    else if (C > 1) wait_vm<4>();
+    else wait_vm<0>();
     __syncthreads();  // chunk 0 is complete
     frags(0, 0);
     int c0 = 0;
