@@ -769,7 +769,53 @@ int run_product(const char* name, long n) {
   return 0;
 }
 
+// ---- lauum's launch pattern on the shipped core: lower-triangle tiles (bi >= bj) of S = T^T T with k from bi*128 to n, `sites` matrices
+// (blockIdx.z), against the same number of flops as uniform-K tiles.  ORDER: 0 = row by row, long k-ranges first (the product's),
+// 1 = the same tiles with every workgroup's k-range cut to the launch's mean (uniform cost, same total flops)
+template <int ORDER>
+__global__ __launch_bounds__(256, 3) void lauum_like_kernel(const double* T, double* S, long n, int nbk, long site_stride) {
+  using D = DmaGemm<double, false, false>;
+  using G = TileGemm<double, false, false, 128, 128>;
+  __shared__ double smem[D::SMEM_ELEMS];
+  T += blockIdx.z * site_stride;
+  S += blockIdx.z * site_stride;
+  int bi, bj;
+  tri_decode(blockIdx.x, bi, bj);
+  typename G::acc_t acc[4][4];
+  G::zero(acc);
+  const int kb = ORDER == 0 ? nbk - bi : (nbk + 2) / 3;  // mean of (nbk - bi) over the triangle ~ nbk / 3 + ...
+  const int row = ORDER == 0 ? bi : 0;
+  const double* base = T + (long)row * 128 * n;
+  D::run(base + (long)bi * 128, n, base + (long)bj * 128, n, kb * 8, smem, acc);
+  double* out = S + (long)bi * 128 * n + (long)bj * 128;
+  G::foreach (acc, [&](int r, int c, double& v) { out[(long)r * n + c] = v; });
+}
+int run_lauum_like(long n, int sites) {
+  double *T, *S;
+  CK(hipMalloc(&T, sites * n * n * 8)); CK(hipMalloc(&S, sites * n * n * 8));
+  CK(hipMemset(T, 0, sites * n * n * 8));
+  const int nbk = (int)(n / 128), tiles = nbk * (nbk + 1) / 2;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  double ktot = 0;  // k-blocks summed over the triangle
+  for (int bi = 0; bi < nbk; ++bi) ktot += (double)(bi + 1) * (nbk - bi);
+  for (int order = 0; order < 2; ++order) {
+    auto k = order == 0 ? lauum_like_kernel<0> : lauum_like_kernel<1>;
+    const double kb_total = order == 0 ? ktot : (double)tiles * ((nbk + 2) / 3);
+    k<<<dim3(tiles, 1, sites), 256>>>(T, S, n, nbk, n * n);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 3; ++r) k<<<dim3(tiles, 1, sites), 256>>>(T, S, n, nbk, n * n);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
+    printf("lauum-like launch n %ld, %d sites, %d tiles per site, %s: %.3f ms  %.1f TF\n", n, sites, tiles,
+           order == 0 ? "triangular k-ranges, long first" : "uniform k-range (the mean)", ms, sites * kb_total * 2.0 * 128 * 128 * 128 / ms / 1e9);
+  }
+  CK(hipFree(T)); CK(hipFree(S));
+  return 0;
+}
+
 int main() {
+  if (getenv("LAUUM_LIKE")) return run_lauum_like(8192, 32);
   if (!getenv("EXPERIMENTS")) {  // default: the shipped core; EXPERIMENTS=1 runs the variants that led to it
     run_product<double, false, false, 2>("f64 IC/IC", 8192);
     if (getenv("ONLY_FIRST")) return 0;
