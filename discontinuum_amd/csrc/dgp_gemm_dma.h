@@ -33,13 +33,13 @@ namespace dgp {
 
 typedef __attribute__((address_space(3))) void* dgp_lds_ptr;
 
-template <typename T, bool A_KC, bool B_KC>
+template <typename T, bool A_KC, bool B_KC, int SLOTS_ = 3>
 struct DmaGemm {
   static constexpr bool F64 = sizeof(T) == 8;
   static constexpr int EPU = 16 / (int)sizeof(T);    // elements per 16-byte unit (what one lane fetches)
   static constexpr int KCH = F64 ? 8 : 16;           // k's per chunk: 64 bytes of a k-contiguous row
   static constexpr int KS = KCH / 4;                 // MFMA k-steps per chunk
-  static constexpr int SLOTS = 3;
+  static constexpr int SLOTS = SLOTS_;               // ring depth in chunks (2 = 32 KB measures 1-2 % slower alone: scripts/gemm_wave.hip)
   static constexpr int AREA = 128 * KCH;             // elements of one operand's chunk (8 KB)
   static constexpr int SLOT_ELEMS = 2 * AREA;        // A then B
   static constexpr int SMEM_ELEMS = SLOTS * SLOT_ELEMS;  // 48 KB
@@ -138,20 +138,20 @@ struct DmaGemm {
     __syncthreads();                  // an earlier use of the ring by this workgroup is over
     issue(0);
     if (C > 1) issue(1);
-    if (C > 2) issue(2);
-    if (C > 2) wait_vm<8>();
+    if (SLOTS > 2 && C > 2) issue(2);
+    if (SLOTS > 2 && C > 2) wait_vm<8>();
     else if (C > 1) wait_vm<4>();
     else wait_vm<0>();
     __syncthreads();  // chunk 0 is complete
     frags(0, 0);
     int c0 = 0;
-    for (; c0 + 2 * SLOTS <= C; c0 += SLOTS) {  // steady state, branch-free: every chunk of the round has a chunk three ahead
+    for (; c0 + 2 * SLOTS <= C; c0 += SLOTS) {  // steady state, branch-free: every chunk of the round has a chunk SLOTS ahead
 #pragma unroll
       for (int u = 0; u < SLOTS; ++u) {
         chunk(u);
-        wait_vm<4>();     // this wave's part of chunk c + 1 has landed (chunk c + 2 may be in flight)
-        __syncthreads();  // ... everyone's has; and everyone has chunk c in registers or behind it
-        issue(u);         // chunk c + 3 into the slot of chunk c
+        wait_vm<4 * (SLOTS - 2)>();  // this wave's part of chunk c + 1 has landed (chunk c + 2 may be in flight)
+        __syncthreads();             // ... everyone's has; and everyone has chunk c in registers or behind it
+        issue(u);                    // chunk c + SLOTS into the slot of chunk c
         frags((u + 1) % SLOTS, 0);
       }
     }
@@ -162,7 +162,7 @@ struct DmaGemm {
         if (c < C) chunk(u);
         wait_vm<0>();
         __syncthreads();
-        if (c + 3 < C) issue(u);
+        if (c + SLOTS < C) issue(u);
         if (c + 1 < C) frags((u + 1) % SLOTS, 0);
       }
     }

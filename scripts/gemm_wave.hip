@@ -716,9 +716,9 @@ int run(const char* name, long n, int K) {
 }
 
 // ---- the PRODUCT's direct-to-LDS core (dgp_gemm_dma.h) against TileGemm, every operand combination, both precisions
-template <typename T, bool AKC, bool BKC>
+template <typename T, bool AKC, bool BKC, int SLOTS = 3>
 __global__ __launch_bounds__(256, 3) void gemm_product_kernel(const T* A, const T* B, T* C, long n, int ktiles) {
-  using D = DmaGemm<T, AKC, BKC>;
+  using D = DmaGemm<T, AKC, BKC, SLOTS>;
   using G = TileGemm<T, AKC, BKC, 128, 128>;
   __shared__ T smem[D::SMEM_ELEMS];
   const long bi = blockIdx.y, bj = blockIdx.x;
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256, 3) void gemm_product_kernel(const T* A, const 
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * n + c] = v; });
 }
 
-template <typename T, bool AKC, bool BKC, int PF>
+template <typename T, bool AKC, bool BKC, int PF, int SLOTS = 3>
 int run_product(const char* name, long n) {
   T *A, *B, *C, *C2;
   CK(hipMalloc(&A, n * n * sizeof(T))); CK(hipMalloc(&B, n * n * sizeof(T))); CK(hipMalloc(&C, n * n * sizeof(T))); CK(hipMalloc(&C2, n * n * sizeof(T)));
@@ -752,18 +752,18 @@ int run_product(const char* name, long n) {
     for (int r = 0; r < reps; ++r) gemm_ref_kernel<T, AKC, BKC, PF><<<grid, 256>>>(A, B, C, n, K / 16);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms_ref, e0, e1)); ms_ref /= reps;
-    gemm_product_kernel<T, AKC, BKC><<<grid, 256>>>(A, B, C2, n, K / 16);
+    gemm_product_kernel<T, AKC, BKC, SLOTS><<<grid, 256>>>(A, B, C2, n, K / 16);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; ++r) gemm_product_kernel<T, AKC, BKC><<<grid, 256>>>(A, B, C2, n, K / 16);
+    for (int r = 0; r < reps; ++r) gemm_product_kernel<T, AKC, BKC, SLOTS><<<grid, 256>>>(A, B, C2, n, K / 16);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms_d, e0, e1)); ms_d /= reps;
     CK(hipMemcpy(c1.data(), C, n * n * sizeof(T), hipMemcpyDeviceToHost)); CK(hipMemcpy(c2.data(), C2, n * n * sizeof(T), hipMemcpyDeviceToHost));
     double md = 0;
     for (long i = 0; i < n * n; ++i) md = fmax(md, fabs((double)c1[i] - (double)c2[i]));
     const double fl = 2.0 * n * n * K / 1e9;
-    printf("product core %-10s n %ld K %5d: TileGemm (PF %d) %.3f ms %6.1f TF | DmaGemm %.3f ms %6.1f TF | max |diff| %.3g\n", name, n, K, PF, ms_ref, fl / ms_ref, ms_d,
-           fl / ms_d, md);
+    printf("product core %-10s n %ld K %5d: TileGemm (PF %d) %.3f ms %6.1f TF | DmaGemm (ring of %d) %.3f ms %6.1f TF | max |diff| %.3g\n", name, n, K, PF, ms_ref, fl / ms_ref,
+           SLOTS, ms_d, fl / ms_d, md);
   }
   CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(C2));
   return 0;
@@ -821,6 +821,7 @@ int main() {
     if (getenv("ONLY_FIRST")) return 0;
     run_product<double, true, false, 1>("f64 KC/IC", 8192);
     run_product<double, true, true, 1>("f64 KC/KC", 8192);
+    run_product<double, true, true, 1, 2>("f64 KC/KC", 8192);  // the ring of two chunks (32 KB)
     run_product<double, false, true, 1>("f64 IC/KC", 8192);
     run_product<float, false, false, 4>("f32 IC/IC", 8192);
     run_product<float, true, false, 4>("f32 KC/IC", 8192);
