@@ -299,6 +299,58 @@ def run_configs(dev, lib, quick):
 
 
 # ------------------------------------------------------------------------------------------ main
+_SAMPLER_SRC = r"""
+import json, subprocess, sys, time
+while True:
+    t = time.time()
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+        c = next(iter(json.loads(r[r.index("{"):]).values()))
+        sclk = int("".join(ch for ch in c.get("sclk clock speed:", "") if ch.isdigit()) or 0)
+        pw = [float(v) for k, v in c.items() if "Power" in k]
+        sys.stdout.write(json.dumps({"t": t, "sclk": sclk, "power": pw[0] if pw else None}) + "\n")
+        sys.stdout.flush()
+    except Exception:
+        pass
+    time.sleep(0.15)
+"""
+
+
+class GpuStateSampler:
+    """Shader clock and package power of GPU 0 (rocm-smi) while the timed region runs: boxes of the pool differ by up to 9 % in
+    every kernel's rate, and this is the only way the line can say which kind it ran on.  The sampling CHILD is started before
+    this process touches the GPU (nothing is exec'ed from a process that has initialised it); failures yield null."""
+
+    def __init__(self):
+        import subprocess
+
+        import atexit
+
+        try:
+            self.proc = subprocess.Popen([sys.executable, "-c", _SAMPLER_SRC], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            atexit.register(lambda p=self.proc: p.poll() is None and p.kill())  # never outlives the bench, whatever ends it
+        except Exception:  # noqa: BLE001
+            self.proc = None
+
+    def window(self, t_start, t_end):
+        if self.proc is None:
+            return None
+        try:
+            self.proc.terminate()
+            lines = self.proc.communicate(timeout=10)[0].splitlines()
+        except Exception:  # noqa: BLE001
+            return None
+        rows = [json.loads(l) for l in lines if l.startswith("{")]
+        rows = [r for r in rows if t_start <= r["t"] <= t_end and r["sclk"] > 0]
+        if not rows:
+            return None
+        clk = [r["sclk"] for r in rows]
+        pw = [r["power"] for r in rows if r["power"] is not None]
+        return {"samples": len(rows), "sclk_mhz": {"min": min(clk), "mean": round(sum(clk) / len(clk), 1), "max": max(clk)},
+                "power_w": ({"min": min(pw), "mean": round(sum(pw) / len(pw), 1), "max": max(pw)} if pw else None),
+                "source": "rocm-smi --showclocks --showpower, every ~0.25 s during the timed region"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +384,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    sampler = GpuStateSampler() if (rank == 0 and args.config == 2 and not args.roofline_only) else None
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     dist = None
@@ -407,10 +460,12 @@ def main():
     for _ in range(args.warmup):
         outs = batch_step()
     barrier()
+    wall0 = time.time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         outs = batch_step()
     torch.cuda.synchronize()
+    wall1 = time.time()
     # the batch gather: (NLL, info, gradient) row of every site -> every rank (RCCL all_gather, 256 B per site)
     local = torch.stack(outs)
     table = gather_site_results(local, world * S) if dist is not None else local
@@ -484,6 +539,7 @@ def main():
                                    f"{S} independent site(s) per GPU in one batched plan (one step = one fit of each)",
                        "n": n, "d": d, "sites_per_gpu": S, "fits_per_step": world * S,
                        "lookahead": not args.no_lookahead, "nll_site0": float(host[0, _lib.OUT_NLL])},
+            "gpu_state": sampler.window(wall0, wall1) if sampler is not None else None,
             "single_site": {"fits_per_s": 1e3 / single_ms, "ms_per_fit": single_ms,
                             "tflops": float(N) ** 3 / (single_ms * 1e-3) / 1e12,
                             "note": "one site alone on one GPU, steps strictly sequential (a single fit loop)"},
