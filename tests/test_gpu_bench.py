@@ -36,6 +36,10 @@ def test_bench_prints_one_contract_line(extra, gpu_device):
     assert len(cpu["steps_s"]) == 2 and cpu["fp32"]["value"] > 0 and cpu["affinity_cores"] >= cpu["cores"]
     assert "configs" not in rec  # only the default n = 8192 run carries the other BASELINE configurations
     assert roof["gram_hbm"]["achieved"] > 0 and roof["gram_grad_hbm"]["achieved"] > 0
+    # the box's state during the timed region: null (rocm-smi unavailable / region shorter than a sample) or clock + power
+    assert "gpu_state" in rec
+    if rec["gpu_state"] is not None:
+        assert 500 < rec["gpu_state"]["sclk_mhz"]["mean"] < 3000 and rec["gpu_state"]["samples"] >= 1
 
 
 # ---------------------------------------------------------------------------------------------------------------------
