@@ -17,6 +17,7 @@ MODEL_LOADEST, MODEL_RATING = 0, 1
 OUT_NLL, OUT_QUAD, OUT_LOGDET, OUT_INFO, OUT_DTHETA, OUT_SUM_DR, OUT_DR_W0, OUT_SUM_DNOISE, OUT_LEN = 0, 1, 2, 3, 4, 28, 29, 31, 32
 BUF_XT, BUF_A, BUF_T, BUF_S, BUF_Z, BUF_ALPHA = range(6)
 BUF_SCAL = 7
+OPT_LAUUM64_MAX_TILES, OPT_SYRK_SLOTS, OPT_TRTRI_SMALL, OPT_REFINE = range(4)
 TIME_GRAM, TIME_POTRF, TIME_SYRK_SUM, TIME_SYRK_N, TIME_TRTRI, TIME_LAUUM, TIME_SOLVE, TIME_GRAD, TIME_SYRK_FLOP, TIME_COUNT = range(10)
 
 
@@ -45,6 +46,8 @@ SIGNATURES = {
     "dgp_plan_workspace_bytes": (_sz, [_vp]),
     "dgp_plan_set_workspace": (_i, [_vp, _vp, _sz]),
     "dgp_plan_set_lookahead": (_i, [_vp, _i]),
+    "dgp_plan_set_option": (_i, [_vp, _i, _i64]),
+    "dgp_plan_get_option": (_i, [_vp, _i, C.POINTER(_i64)]),
     "dgp_plan_set_batch": (_i, [_vp, _i]),
     "dgp_plan_batch": (_i, [_vp]),
     "dgp_plan_set_site_sizes": (_i, [_vp, C.POINTER(C.c_int64), _vp]),
@@ -90,6 +93,7 @@ SIGNATURES = {
     "dgp_stage_solve": (_i, [_vp, _vp, _vp]),
     "dgp_stage_grad": (_i, [_vp, _dp, _vp, _vp]),
     "dgp_cross_gram": (_i, [_vp, _dp, _vp, _i64, _vp, _vp, _vp]),
+    "dgp_debug_tile_gemm": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -98,6 +98,16 @@ class GPPlan:
         level = 2 if level is True else int(level)
         _lib.check(self.lib.dgp_plan_set_lookahead(self._h, level), "dgp_plan_set_lookahead")
 
+    def set_option(self, key: int, value: int):
+        """Plan-level option (``_lib.OPT_*``; include/dgp_hip.h ``dgp_plan_set_option``): tile-shape selectors of the
+        O(n^3) stages and the float32 refinement switch."""
+        _lib.check(self.lib.dgp_plan_set_option(self._h, int(key), int(value)), "dgp_plan_set_option")
+
+    def get_option(self, key: int) -> int:
+        v = C.c_int64()
+        _lib.check(self.lib.dgp_plan_get_option(self._h, int(key), C.byref(v)), "dgp_plan_get_option")
+        return int(v.value)
+
     def _check_vec(self, t, name, length=None):
         length = (self.n if length is None else length) * self.batch
         if not (torch.is_tensor(t) and t.is_cuda and t.dtype == self.dtype and t.is_contiguous() and t.numel() == length):

@@ -70,7 +70,10 @@ struct dgp_plan {
   int B;                  // sites carried in lockstep (1 = plain plan); site b's buffers sit b * site_bytes further on
   size_t site_bytes;
   void* pre;              // device scratch for the batch's hyperparameters (B > 8), after the last site
+  void* pre2;             // a second one for the fp64 evaluator of the refinement (fp32 plans), so that `pre` stays valid
   int pre_ready;          // the Gram build of the current step has uploaded them
+  Tuning tune;            // tile-shape selectors (dgp_plan_set_option)
+  int refine;             // fp32 plans: one step of iterative refinement with an fp64 residual after the solves
   int* nsite;             // device: the sites' own sizes (B > 1), after the hyperparameter scratch
   const void* dr_w;       // caller's [2][n] weight vectors for the out[DGP_OUT_DR_W0..] reductions, or null
   int64_t n, N;
@@ -181,6 +184,8 @@ int dgp_plan_create(int model, int dtype, int64_t n, int d, dgp_plan** out) {
   p->B = 1;
   p->lookahead = default_lookahead();
   p->early = getenv("DGP_NO_EARLY_TRTRI") ? 0 : 1;
+  p->tune = default_tuning();
+  p->refine = (dtype == DGP_F32 && !(getenv("DGP_NO_REFINE") && atoi(getenv("DGP_NO_REFINE")))) ? 1 : 0;
   *out = p;
   return 0;
 }
@@ -209,7 +214,7 @@ int dgp_plan_destroy(dgp_plan* p) {
 }
 
 size_t dgp_plan_workspace_bytes(const dgp_plan* p) {
-  return p ? layout(p).total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)) + (p->B > 1 ? align_up(sizeof(int) * p->B) : 0)
+  return p ? layout(p).total * (size_t)p->B + 2 * align_up(pre_scratch_bytes(p->B)) + (p->B > 1 ? align_up(sizeof(int) * p->B) : 0)
            : 0;
 }
 
@@ -268,10 +273,11 @@ int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   p->info = (int*)(p->ws + L.info);
   p->snap = p->ws + L.snap;
   p->pre = pre_scratch_bytes(p->B) ? (void*)(p->ws + L.total * (size_t)p->B) : nullptr;
+  p->pre2 = p->pre ? (void*)((char*)p->pre + align_up(pre_scratch_bytes(p->B))) : nullptr;
   p->nsite = nullptr;
   p->dr_w = nullptr;
   if (p->B > 1) {  // every site starts at the full size n
-    p->nsite = (int*)(p->ws + L.total * (size_t)p->B + align_up(pre_scratch_bytes(p->B)));
+    p->nsite = (int*)(p->ws + L.total * (size_t)p->B + 2 * align_up(pre_scratch_bytes(p->B)));
     delete[] p->nsite_host;
     p->nsite_host = new (std::nothrow) int[(size_t)p->B];
     if (!p->nsite_host) return fail(DGP_E_ARG, "dgp_plan_set_workspace: out of host memory");
@@ -281,6 +287,40 @@ int dgp_plan_set_workspace(dgp_plan* p, void* dev_ptr, size_t bytes) {
   }
   p->have_inputs = p->have_factor = 0;
   return 0;
+}
+
+int dgp_plan_set_option(dgp_plan* p, int key, int64_t value) {
+  if (!p) return fail(DGP_E_ARG, "dgp_plan_set_option: null plan");
+  switch (key) {
+    case DGP_OPT_LAUUM64_MAX_TILES:
+      if (value < 0 || value > (1 << 30)) return fail(DGP_E_ARG, "dgp_plan_set_option: value out of range");
+      p->tune.lauum64_max_tiles = (int)value;
+      return 0;
+    case DGP_OPT_SYRK_SLOTS:
+      if (value < 1 || value > (1 << 20)) return fail(DGP_E_ARG, "dgp_plan_set_option: value out of range");
+      p->tune.syrk_slots = (int)value;
+      return 0;
+    case DGP_OPT_TRTRI_SMALL:
+      if (value < 0) return fail(DGP_E_ARG, "dgp_plan_set_option: value out of range");
+      p->tune.trtri_small = (long)value;
+      return 0;
+    case DGP_OPT_REFINE:
+      if (p->dtype != DGP_F32 && value) return fail(DGP_E_ARG, "dgp_plan_set_option: refinement applies to float32 plans");
+      p->refine = value ? 1 : 0;
+      return 0;
+    default:
+      return fail(DGP_E_ARG, "dgp_plan_set_option: unknown option");
+  }
+}
+int dgp_plan_get_option(const dgp_plan* p, int key, int64_t* value) {
+  if (!p || !value) return fail(DGP_E_ARG, "dgp_plan_get_option: null argument");
+  switch (key) {
+    case DGP_OPT_LAUUM64_MAX_TILES: *value = p->tune.lauum64_max_tiles; return 0;
+    case DGP_OPT_SYRK_SLOTS: *value = p->tune.syrk_slots; return 0;
+    case DGP_OPT_TRTRI_SMALL: *value = p->tune.trtri_small; return 0;
+    case DGP_OPT_REFINE: *value = p->refine; return 0;
+    default: return fail(DGP_E_ARG, "dgp_plan_get_option: unknown option");
+  }
 }
 
 int dgp_plan_set_lookahead(dgp_plan* p, int level) {
@@ -512,6 +552,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const T* scal, int* info, l
       logdet = *reinterpret_cast<const double*>(scal + 2);
       quad = *reinterpret_cast<const double*>(scal + 4);
     }
+    if (info[0] < 0) quad = __builtin_nan("");  // the split chain gave up waiting (dgp_chol.hip::chain_wait): no factor
     out[DGP_OUT_NLL] = (T)(0.5 * quad + 0.5 * logdet + 0.5 * 1.83787706640934548356 * (double)n);
     out[DGP_OUT_QUAD] = (T)quad;
     out[DGP_OUT_LOGDET] = (T)logdet;
@@ -528,6 +569,7 @@ static Batch batch_of(const dgp_plan* p) {
   bt.B = p->B;
   bt.ws = (long)(p->site_bytes / sizeof(T));  // layout offsets are multiples of 256 bytes
   bt.ns = p->nsite;
+  bt.tune = &p->tune;
   return bt;
 }
 template <typename T>
@@ -546,7 +588,7 @@ static int run_potrf(dgp_plan* p, hipStream_t s) {
   if ((rc = ensure_timing(p)) || (rc = ensure_split(p, s))) return rc;
   if (split_applies(p) && p->sc)
     return potrf_split<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, (T*)p->snap, s, p->sc, p->s2, p->ev,
-                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr, split_start(p), group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST));
+                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr, split_start(p), group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), &p->tune);
   return potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), s, p->s2, p->ev,
                   p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 0, nullptr, nullptr, nullptr, nullptr,
                   batch_of<T>(p));
@@ -564,6 +606,38 @@ static int run_solve(dgp_plan* p, const void* r, hipStream_t s) {
   return solve<T>((const T*)p->Tm, p->N, (const T*)r, (int)p->n, (T*)p->z, (T*)p->alpha, (T*)p->spart,
                   (T*)p->scal + 1, s, batch_of<T>(p));
 }
+// fp32 plans: one step of iterative refinement of alpha and of the quadratic form with an fp64 residual (SURVEY.md section
+// 8d's fp32 row as written; the reference trains in float32, src/discontinuum/engines/gpytorch.py:221-222, 350-353).
+// The factor is stored in fp32, so alpha0 = T^T T r carries cond(K^) eps32 (2.4e-3 at config 3) and the quadratic form
+// 1e-5 of itself -- more than the whole NLL tolerance when its three terms cancel.  rho = r - K^ alpha0 in double with K^
+// re-evaluated on the fly (gram_residual), delta from the fp32 factor, alpha = alpha0 + delta, quad second-order accurate
+// (refine_finish_kernel).  The scratch lives in S, which is free between the solves and lauum (trtri's W is consumed).
+template <typename T>
+static int run_refine(dgp_plan* p, const double* theta, const void* r, const void* noise, hipStream_t s) {
+  if constexpr (sizeof(T) != 4) {
+    return 0;
+  } else {
+    if (!p->refine) return 0;
+    const long N = p->N;
+    const size_t nb = (size_t)(N / 64), part_bytes = nb * nb * 64 * sizeof(double);
+    if (gram_residual_scratch_bytes(N) > (size_t)N * N * sizeof(float)) return 0;  // (never: N >= 128)
+    char* base = (char*)p->S;
+    double* part = (double*)base;
+    double* rho64 = (double*)(base + part_bytes);
+    float* rho32 = (float*)(base + part_bytes + (size_t)N * sizeof(double));
+    float* delta = rho32 + N;
+    const Batch bt = batch_of<float>(p);
+    const long ps = bt.ws / 2;  // site stride of S in doubles (bt.ws floats, a multiple of 64)
+    void* staging = p->pre2 ? p->ring.acquire(pre_scratch_bytes(p->B)) : nullptr;
+    int rc = gram_residual<float>(p->model, p->d, (const float*)p->Xt, N, (int)p->n, theta, (const float*)noise, (const float*)r,
+                                  (const float*)p->alpha, part, rho64, rho32, s, bt, ps, bt.ws, p->pre2, staging);
+    if (staging) p->ring.commit(s);
+    if (rc) return rc;
+    return refine_solve<float>((const float*)p->Tm, N, (const float*)r, (int)p->n, rho64, rho32, (float*)p->z, delta,
+                               (float*)p->alpha, (float*)p->spart, (float*)p->scal + 1, s, bt, ps, bt.ws);
+  }
+}
+
 template <typename T>
 static int run_grad(dgp_plan* p, const double* theta, void* dtheta, hipStream_t s) {
   return gram_grad<T>(p->model, p->d, (const T*)p->Xt, p->N, (int)p->n, theta, (const T*)p->S, (const T*)p->alpha,
@@ -606,22 +680,22 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
       hipStreamWaitEvent(e->p->s3, e->p->xev[c], 0);
       const int rc = trtri_advance<T>((const T*)e->p->A, e->p->N, (T*)e->p->Tm, (T*)e->p->S, e->ck[c], &e->st,
                                       e->p->s3, EARLY_WG_CAP, e->p->info + EARLY_CTR0, EARLY_CTR_PAIRS,
-                                      EARLY_RESERVED_CUS);
+                                      EARLY_RESERVED_CUS, batch_of<T>(e->p));
       if (rc && !e->rc) e->rc = rc;
     };
     if ((rc = ensure_timing(p)) || (rc = ensure_split(p, s))) return rc;
     if (split_applies(p) && p->sc)
       rc = potrf_split<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, (T*)p->snap, s, p->sc, p->s2, p->ev,
-                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx, split_start(p), group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST));
+                          p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx, split_start(p), group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), &p->tune);
     else
       rc = potrf<T>((T*)p->A, p->N, (T*)p->Tm, (T*)p->scal, p->info, group_size(p->lookahead, p->B, p->N / DGP_TILE_HOST), s, p->s2, p->ev,
-                    p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx);
+                    p->timing ? p->sev : nullptr, &p->n_syrk, &p->syrk_flop, 3, ctx.ck, p->xev, on_ck, &ctx, bt);
     if (rc || (rc = ctx.rc)) return rc;
     tick(p, TS_POTRF, 1, s);
     tick(p, TS_TRTRI, 0, s);
     hipEventRecord(p->xev[3], s);  // factorisation complete (s has joined the bulk stream)
     hipStreamWaitEvent(p->s3, p->xev[3], 0);
-    if ((rc = trtri_advance<T>((const T*)p->A, p->N, (T*)p->Tm, (T*)p->S, nbk, &ctx.st, p->s3, 0, nullptr, 0, 0)))
+    if ((rc = trtri_advance<T>((const T*)p->A, p->N, (T*)p->Tm, (T*)p->S, nbk, &ctx.st, p->s3, 0, nullptr, 0, 0, bt)))
       return rc;
     hipEventRecord(p->xev[4], p->s3);
     hipStreamWaitEvent(s, p->xev[4], 0);
@@ -635,6 +709,7 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
   }
   tick(p, TS_SOLVE, 0, s);
   if ((rc = run_solve<T>(p, r, s))) return rc;
+  if ((rc = run_refine<T>(p, theta, r, noise, s))) return rc;
   tick(p, TS_SOLVE, 1, s);
   p->timed_valid = 0;
   p->have_inverse = 0;

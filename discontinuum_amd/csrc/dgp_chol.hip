@@ -34,17 +34,54 @@ struct Prefetch {
 };
 
 // ------------------------------------------------------------------------------------------
+// In-kernel waits of the split panel chain (potrf_split): a kernel polls a progress word that ANOTHER kernel publishes.
+// That is only safe while the producer gets dispatched beside the waiter -- true for the hardware queues of distinct
+// streams, NOT for a tool that serialises dispatches in queue-ready order (rocprofv3 --pmc does: a waiter granted first
+// would spin forever; counter passes on single-site plans must run with DGP_SPLIT_CHAIN=0, scripts/collect_profiles.sh
+// exports it) and not after a failed producer launch (checked on the host before the waiter is enqueued).  So every wait
+// is BOUNDED: after CHAIN_WAIT_TICKS of the 100 MHz wall clock (2 s -- a whole n = 8192 fit takes 12 ms) the waiter
+// writes DGP_INFO_CHAIN_TIMEOUT into info[0] and its workgroup returns without touching the matrix; every later waiter
+// sees the code and returns at once, so the chain drains in about one budget, the result row carries info < 0 and a NaN
+// NLL (finish_kernel) instead of the device hanging.
+#define DGP_INFO_CHAIN_TIMEOUT (-7)
+#define CHAIN_WAIT_TICKS 200000000LL
+__device__ __forceinline__ bool chain_reached(const int* word, int value) {
+  return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= value;
+}
+// thread 0 polls, the workgroup follows; -> false: give up (timeout, or an earlier waiter's timeout)
+__device__ __forceinline__ bool chain_wait(const int* w0, int v0, const int* w1, int v1, int* info) {
+  __shared__ int chain_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    if (!(chain_reached(w0, v0) && (w1 == nullptr || chain_reached(w1, v1)))) {
+      const long long t0 = wall_clock64();
+      while (!(chain_reached(w0, v0) && (w1 == nullptr || chain_reached(w1, v1)))) {
+        if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DGP_INFO_CHAIN_TIMEOUT) {
+          ok = 0;
+          break;
+        }
+        if (wall_clock64() - t0 > CHAIN_WAIT_TICKS) {
+          __hip_atomic_store(info, DGP_INFO_CHAIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    chain_ok = ok;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return chain_ok != 0;
+}
+
 // A[i,k] <- A[i,k] * L_kk^-T  (L_kk^-1 lives in the diagonal block of Tinv).  This kernel sits on the
 // sequential panel chain, so it uses 64-row tiles: twice the workgroups, half the per-workgroup latency.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T* __restrict__ Tinv, long ld, int k,
-                                                      long bs, const int* __restrict__ wait_word = nullptr, int wait_value = 0) {
-  if (wait_word) {  // split panel chain: launched on the rest stream BEFORE diag(k) has finished; see potrf_split
-    if (threadIdx.x == 0)
-      while (__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_value) __builtin_amdgcn_s_sleep(8);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
+                                                      long bs, int* __restrict__ wait_info = nullptr, int wait_value = 0) {
+  // split panel chain: launched on the rest stream BEFORE diag(k) has finished (wait_info = the plan's info words)
+  if (wait_info && !chain_wait(wait_info + CHAIN_DIAG_DONE, wait_value, nullptr, 0, wait_info)) return;
   A = site(A, bs);
   Tinv = site(Tinv, bs);
   // 64 rows x all 128 panel columns per workgroup: a workgroup only ever reads the rows it overwrites
@@ -63,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T
 // (bulk trailing update; nk = 2 halves the passes over the trailing matrix: 53.6 vs 44.5 TFLOP/s in isolation).
 // How C joins the accumulators differs by precision: trailing_begin / trailing_end below.
 //
-// All tiles cost the same and the GPU holds 512 (fp64: 768) of these workgroups at a time, so a launch of t tiles runs in
+// All tiles cost the same and the round cut assumes 512 workgroup slots (Tuning::syrk_slots), so a launch of t tiles runs in
 // ceil(t / slots) rounds and its last round is on average half empty.  The first `nfull` tiles (whole rounds) are
 // done as 128 x 128 tiles; the rest is cut into `split` pieces each (2: 64 x 128 halves, 4: 64 x 64 quarters),
 // which fills the last round at a fraction of its time (SyrkShape picks the cheapest cut).
@@ -104,17 +141,25 @@ __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kern
   }
 }
 
-// workgroups of the bulk update the GPU holds at a time: 256 CUs x the tile core's occupancy
-template <typename T>
-static int syrk_slots() {
-  static const int v = getenv("DGP_SYRK_SLOTS") ? atoi(getenv("DGP_SYRK_SLOTS")) : 512;
-  return v;
+// The selectors' defaults (Tuning, dgp_internal.h).  syrk_slots: 512 measured best for both precisions -- with the
+// direct-to-LDS core the GPU holds 768 of these workgroups at a time, and cutting the rounds at 768 changes nothing measurable.
+const Tuning& default_tuning() {
+  static const Tuning t = [] {
+    Tuning v;
+    v.lauum64_max_tiles = getenv("DGP_LAUUM64") ? atoi(getenv("DGP_LAUUM64")) : 1000;
+    v.syrk_slots = getenv("DGP_SYRK_SLOTS") ? atoi(getenv("DGP_SYRK_SLOTS")) : 512;
+    v.trtri_small = getenv("DGP_TRTRI_SMALL") ? atol(getenv("DGP_TRTRI_SMALL")) : 1024;
+    if (v.syrk_slots < 1) v.syrk_slots = 1;
+    return v;
+  }();
+  return t;
 }
 // grid shape of one bulk launch: whole rounds of full tiles + the remainder cut into `split` pieces
 struct SyrkShape {
   int nfull, split;
   unsigned grid;
   explicit SyrkShape(int ntiles, int slots = 512) {
+    if (slots < 1) slots = 1;  // (slots / batch of a large batch)
     // relative cost of one round of 128x128 / 64x128 / 64x64 tiles (the small ones reach ~87 % of the big tile's rate)
     const double cost[5] = {0, 1.0, 0.55, 0, 0.30};
     const int whole = ntiles / slots * slots, rem = ntiles - whole;
@@ -173,6 +218,19 @@ __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_col1
 // the trailing updates sum from zero (dgp_gemm.h::trailing_begin) the fp64 block changes neither the log-determinant
 // nor the quadratic form's error (which is then set by L being STORED in fp32), and costs 2 % (n = 16384) to 12 %
 // (n = 2048) of a fit step.  Kept as a measurement knob.
+// true the first time it is asked on the calling thread's current device (a per-device "configured" flag)
+struct DeviceOnce {
+  std::mutex mtx;
+  bool seen[64] = {false};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown: configure every time (cheap)
+    std::lock_guard<std::mutex> lock(mtx);
+    const bool f = !seen[dev];
+    seen[dev] = true;
+    return f;
+  }
+};
 static bool f32_diag64() {
   static const bool v = [] {
     const char* e = getenv("DGP_F32_DIAG64");
@@ -183,13 +241,13 @@ static bool f32_diag64() {
 template <typename TS, typename TC>
 static void launch_diag_as(TS* A, long N, long k0, TS* Tinv, TS* logdet, int* info, hipStream_t s, Batch bt, bool init,
                            double* logdet_hi, int done_index, int done_value) {
-  static bool configured = false;
+  // the opt-in for > 64 KB of dynamic LDS belongs to the CURRENT DEVICE's function object: keyed by device, so that a
+  // process that drives plans on several GPUs opts in on each (a failure surfaces as the launch error below it)
   const size_t bytes = potrf_diag_fast_smem<TC>();
-  if (!configured) {
+  static DeviceOnce configured;
+  if (configured.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_fast_kernel<TS, TC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    configured = true;
-  }
   potrf_diag_fast_kernel<TS, TC><<<dim3(1, 1, (unsigned)bt.B), 256, bytes, s>>>(
       A, N, k0, Tinv, logdet, info, bt.ws, bt.ws * (long)sizeof(TS) / (long)sizeof(int), init ? 1 : 0, POTRF_INFO_INTS, logdet_hi,
       done_index, done_value);
@@ -235,7 +293,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, Bz), 256, 0, s>>>(A, Tinv, N, k, bt.ws);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
         {
-          const SyrkShape sh((int)tri(nbk - k - 1), syrk_slots<T>() / bt.B);
+          const SyrkShape sh((int)tri(nbk - k - 1), bt.tuning().syrk_slots / bt.B);
           syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s>>>(A, N, k, 1, k + 1, sh.nfull, sh.split, bt.ws);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s);
@@ -282,7 +340,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         hipStreamWaitEvent(s2, P[q - 1], 0);
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
         {
-          const SyrkShape sh((int)tri(nbk - k0 - G), syrk_slots<T>() / bt.B);
+          const SyrkShape sh((int)tri(nbk - k0 - G), bt.tuning().syrk_slots / bt.B);
           syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s2>>>(A, N, k0 - G, G, k0 + G, sh.nfull, sh.split, bt.ws);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
@@ -343,7 +401,7 @@ __global__ __launch_bounds__(256) void snap_copy_kernel(const T* __restrict__ A,
 template <typename T>
 __global__ __launch_bounds__(256) void crit_kernel(T* __restrict__ A, long ld, int k, const T* __restrict__ Tinv,
                                                    const T* __restrict__ snap, int nfinal, int first_final, int solve_,
-                                                   const int* __restrict__ flags, int need_rest, int need_bulk) {
+                                                   int* __restrict__ info, int need_rest, int need_bulk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char crit_smem[];
   using acc_t = typename Mfma<T>::acc_t;
   T* sX = reinterpret_cast<T*>(crit_smem);   // DGP_DTRI sub-blocks
@@ -357,14 +415,9 @@ __global__ __launch_bounds__(256) void crit_kernel(T* __restrict__ A, long ld, i
   // enqueued long before this launch and have normally finished long ago -- an event wait in front of this kernel would
   // cost the critical stream ~11 us per panel for nothing (measured: profiles/r03_split_chain.txt), so the kernel checks
   // two counters itself: flags[0] = rest steps finished, flags[1] = bulk launches finished (one-thread signal kernels
-  // behind them).  The producers never depend on anything this kernel does.
-  if (t == 0) {
-    while (__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_rest ||
-           __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_bulk)
-      __builtin_amdgcn_s_sleep(8);
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // behind them).
+  // The producers never depend on anything this kernel does; the wait is bounded (chain_wait above).
+  if (!chain_wait(info + CHAIN_FLAG0, need_rest, info + CHAIN_FLAG0 + 1, need_bulk, info)) return;
   T* Akk = A + (long)k * NB * ld + (long)k * NB;
   // strip s (0..3) = 16 rows of the block: strips 0,1 = the tile's rows (ti), strips 2,3 = its columns' rows (tj)
   const int srow = (wave < 2 ? 2 * ti + wave : 2 * tj + (wave - 2)) * 16;  // first row (inside the block) of this wave's strip
@@ -458,8 +511,11 @@ __global__ __launch_bounds__(256) void crit_kernel(T* __restrict__ A, long ld, i
       *c = sizeof(T) == 8 ? acc[r] : *c - acc[r];
     }
 }
-__global__ void chain_signal_kernel(int* word, int value) {
-  if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+__global__ void chain_signal_kernel(int* word, int value, int* also_zero = nullptr) {
+  if (threadIdx.x == 0) {
+    if (also_zero) __hip_atomic_store(also_zero, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 template <typename T>
 static size_t crit_smem_bytes() { return (size_t)(DGP_DTRI + 16) * DGP_DBLK * sizeof(T); }
@@ -522,23 +578,24 @@ __global__ __launch_bounds__(256, 2) void chain_col_kernel(T* __restrict__ A, lo
 template <typename T>
 int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_t s, hipStream_t c2, hipStream_t s2,
                 hipEvent_t* ev /* 3 nbk */, hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop, int nck, const int* ck_blocks,
-                hipEvent_t* ck_ev, void (*on_ck)(void*, int), void* ck_ctx, int k_start, int G_old) {
+                hipEvent_t* ck_ev, void (*on_ck)(void*, int), void* ck_ctx, int k_start, int G_old, const Tuning* tune) {
   const int nbk = (int)(N / NB);
+  Batch bt;
+  bt.tune = tune;
   if (G_old < 2) G_old = 2;
   if (k_start < 0) k_start = 0;
   k_start = (k_start + G_old - 1) / G_old * G_old;  // a group boundary of the schedule that runs first (G_old is even)
   if (k_start + 4 > nbk)  // nothing left for the split chain
-    return potrf<T>(A, N, Tinv, logdet, info, G_old, s, s2, ev, syrk_ev, n_syrk, syrk_flop, nck, ck_blocks, ck_ev, on_ck, ck_ctx);
+    return potrf<T>(A, N, Tinv, logdet, info, G_old, s, s2, ev, syrk_ev, n_syrk, syrk_flop, nck, ck_blocks, ck_ev, on_ck, ck_ctx, bt);
   PotrfCarry carry;
-  const Batch bt;
   hipEvent_t* ED = ev;            // diag(k) done, on s
   hipEvent_t* ER = ev + nbk;      // R(k) done, on c2
   hipEvent_t* U = ev + 2 * nbk;   // bulk(q) done, on s2
-  static bool configured[2] = {false, false};
   const size_t cbytes = crit_smem_bytes<T>();
-  if (!configured[sizeof(T) == 8]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&crit_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbytes);
-    configured[sizeof(T) == 8] = true;
+  static DeviceOnce configured;  // one per instantiation (T), keyed by device
+  if (configured.first()) {
+    const hipError_t ce = hipFuncSetAttribute(reinterpret_cast<const void*>(&crit_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbytes);
+    if (ce != hipSuccess) return (int)ce;
   }
   int ck_next = 0;
   int ns = 0, last_u = -1;
@@ -547,7 +604,7 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
   if (k_start > 0) {
     const int q0 = k_start / G_old;
     const int rc = potrf<T>(A, N, Tinv, logdet, info, G_old, s, s2, ev, syrk_ev, n_syrk, syrk_flop, nck, ck_blocks, ck_ev, on_ck,
-                            ck_ctx, Batch(), q0, &carry);
+                            ck_ctx, bt, q0, &carry);
     if (rc) return rc;
     ck_next = carry.ck_next;
     ns = carry.ns;
@@ -570,7 +627,7 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
     if (kfirst < 0) kfirst = k - 1;
     hipStreamWaitEvent(s2, ER[k], 0);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
-    const SyrkShape sh((int)tri(nbk - k - 3), syrk_slots<T>());
+    const SyrkShape sh((int)tri(nbk - k - 3), bt.tuning().syrk_slots);
     syrk_kernel<T><<<dim3(sh.grid, 1, 1), 256, 0, s2>>>(A, N, kfirst, nk, k + 3, sh.nfull, sh.split, 0);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
     flop += (double)nk * tile_flop * tri(nbk - k - 3);
@@ -583,7 +640,7 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
     // The rest stream's first trsm polls info[CHAIN_DIAG_DONE], which still holds the LAST step's final value until this
     // factorisation's first diagonal-block kernel resets the status words: clear it here, on s, and let c2 start behind
     // that (one event per factorisation; without it trsm(0) could run ahead of diag(0) on stale data)
-    chain_signal_kernel<<<1, 64, 0, s>>>(info + CHAIN_DIAG_DONE, 0);
+    chain_signal_kernel<<<1, 64, 0, s>>>(info + CHAIN_DIAG_DONE, 0, info);  // (and info[0]: a stale time-out code would make the waiters leave)
     hipEventRecord(ED[0], s);
     hipStreamWaitEvent(c2, ED[0], 0);
     snap_copy_kernel<T><<<8, 256, 0, s>>>(A, N, 1, 0, snap + (long)NB * NB);  // rows of block 1 of panel 0, before their trsm
@@ -614,15 +671,18 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
       const int need_rest = k >= 2 ? k - 1 : 0, need_bulk = ((k & 1) == 0 && k >= 4 && bulk_exists(k / 2 - 2)) ? k / 2 - 1 : 0;
       const bool handed = k == k_start && k_start > 0;  // every pending panel of this block was solved by the group schedule
       const int nfinal = handed ? G_old : ((k & 1) ? 0 : 1), first_final = handed ? k_start - G_old : k - 2;
-      crit_kernel<T><<<10, 256, cbytes, s>>>(A, N, k, Tinv, snap + (long)(k & 1) * NB * NB, nfinal, first_final, handed ? 0 : 1, flags,
+      crit_kernel<T><<<10, 256, cbytes, s>>>(A, N, k, Tinv, snap + (long)(k & 1) * NB * NB, nfinal, first_final, handed ? 0 : 1, info,
                                             need_rest, need_bulk);
     }
     // diag(k) publishes info[CHAIN_DIAG_DONE] = k + 1 itself; the rest stream's trsm(k) is launched right away and polls
     // that word: no event record / stream wait between the critical kernels (each costs the stream ~3 us)
     launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt, k == 0, CHAIN_DIAG_DONE, k + 1);
+    // trsm(k) polls a word that diag(k) publishes: never enqueue the waiter behind a producer whose launch failed
+    // (both critical kernels need opted-in dynamic LDS) -- that would turn an error code into a 2 s stall
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess) return (int)le;
     if (k + 1 >= nbk) break;
     // ---- rest stream
-    trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, 1), 256, 0, c2>>>(A, Tinv, N, k, 0, info + CHAIN_DIAG_DONE, k + 1);
+    trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, 1), 256, 0, c2>>>(A, Tinv, N, k, 0, info, k + 1);
     const int q = k >> 1;
     ChainJobs jobs;
     if ((k & 1) == 0) {  // first panel of pair q: column k+1 (below its diagonal block) <- panel k; snapshot block row k+2
@@ -835,8 +895,7 @@ static void trtri_level(const T* L, T* Tm, T* W, long N, long ld, int mblk, int 
     const int rows = nbk128 - (2 * mblk * g + mblk);
     tiles += (long)(rows < mblk ? (rows > 0 ? rows : 0) : mblk) * mblk;
   }
-  static const long small_lim = getenv("DGP_TRTRI_SMALL") ? atol(getenv("DGP_TRTRI_SMALL")) : 1024;
-  const bool small = tiles * bt.B < small_lim;
+  const bool small = tiles * bt.B < bt.tuning().trtri_small;
   const int m = small ? 2 * mblk : mblk, ntile = (int)(N / (small ? 64 : 128));
   const bool queue = early != nullptr && early->pairs_left > 0 && m * m * ng > early->wg_cap;
   if (!queue) {
@@ -910,7 +969,10 @@ __global__ __launch_bounds__(256, (TileCore<T, false, false>::OCC)) void lauum_k
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
   const T* base = Tm + (long)bi * NB * ld;
-  K::run(base + (long)bi * NB, ld, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc);
+  // k from the LAST row block up to the diagonal block (REV): the rows of L^-1 far below the diagonal hold its smallest
+  // entries, and thousands of tiny products added to a sum that already holds the diagonal block's large ones are
+  // rounded away in fp32 -- small-to-large keeps them (dgp_gemm.h::run)
+  K::template run<true>(base + (long)bi * NB, ld, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc);
   T* out = S + (long)bi * NB * ld + (long)bj * NB;
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
 }
@@ -928,24 +990,16 @@ __global__ __launch_bounds__(256, 2) void lauum64_kernel(const T* __restrict__ T
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
   const T* base = Tm + (long)bi * 64 * ld;
-  G::run(base + (long)bi * 64, ld, base + (long)bj * 64, ld, (nb64 - bi) * (64 / 16), smem, acc);
+  G::template run<1, true>(base + (long)bi * 64, ld, base + (long)bj * 64, ld, (nb64 - bi) * (64 / 16), smem, acc);
   T* out = S + (long)bi * 64 * ld + (long)bj * 64;
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
-}
-
-static int lauum64_max_tiles() {
-  static const int v = [] {
-    const char* e = getenv("DGP_LAUUM64");
-    return e ? atoi(e) : 1000;
-  }();
-  return v;
 }
 
 template <typename T>
 int lauum(const T* Tm, long N, T* S, hipStream_t s, Batch bt) {
   const int nbk = (int)(N / NB);
   const int tiles = nbk * (nbk + 1) / 2;
-  if ((long)tiles * bt.B <= lauum64_max_tiles()) {  // fewer 128-tiles than CUs
+  if ((long)tiles * bt.B <= bt.tuning().lauum64_max_tiles) {  // fewer 128-tiles than CUs
     const int nb64 = 2 * nbk;
     lauum64_kernel<T><<<dim3((unsigned)(nb64 * (nb64 + 1) / 2), 1, (unsigned)bt.B), 256, 0, s>>>(Tm, S, N, nb64, bt.ws);
   } else {
@@ -958,10 +1012,10 @@ int lauum(const T* Tm, long N, T* S, hipStream_t s, Batch bt) {
 // z_i = sum_{j <= i} T[i][j] r_j : one wave per row (coalesced along j)
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_n_kernel(const T* __restrict__ Tm, long ld, const T* __restrict__ r, int n,
-                                                     T* __restrict__ z, long bs, const int* __restrict__ ns) {
+                                                     T* __restrict__ z, long bs, const int* __restrict__ ns, long rs) {
   Tm = site(Tm, bs);
   z = site(z, bs);
-  r = site(r, (long)n);
+  r = site(r, rs);  // site stride of r: n for the caller's residuals, the scratch stride for the refinement's rho
   n = site_n(ns, n);
   const int lane = threadIdx.x & 63;
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -996,12 +1050,14 @@ __global__ __launch_bounds__(256) void trmv_t_kernel(const T* __restrict__ Tm, l
   if (ty == 0) partial[(long)blockIdx.y * ld + j] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
-// alpha[j] = sum over the row chunks; the LAST workgroup instead computes quad = z^T z (one launch less)
+// alpha[j] = sum over the row chunks; the LAST workgroup instead computes quad = z^T z (one launch less; quad == null:
+// the refinement's second solve, whose quadratic form comes from refine_finish_kernel)
 template <typename T>
 __global__ __launch_bounds__(256) void trmv_t_reduce_kernel(const T* __restrict__ partial, long N, int nchunks,
                                                             T* __restrict__ alpha, long bs, int chunk,
-                                                            const T* __restrict__ z, T* __restrict__ quad) {
+                                                            const T* __restrict__ z, T* __restrict__ quad, long as = -1) {
   if (blockIdx.x == gridDim.x - 1) {
+    if (quad == nullptr) return;
     z = site(z, bs);
     quad = site(quad, bs);
     // accumulated in double whatever T is (fp32 plans: the sum of up to 2^20 squares would otherwise lose ~3 digits);
@@ -1022,7 +1078,7 @@ __global__ __launch_bounds__(256) void trmv_t_reduce_kernel(const T* __restrict_
     return;
   }
   partial = site(partial, bs);
-  alpha = site(alpha, bs);
+  alpha = site(alpha, as >= 0 ? as : bs);
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= N) return;
   T acc = T(0);
@@ -1101,12 +1157,62 @@ long solve_partials(long N) { return (N + trmv_chunk(N) - 1) / trmv_chunk(N) * N
 template <typename T>
 int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T* quad, hipStream_t s, Batch bt) {
   const unsigned Bz = (unsigned)bt.B;
-  trmv_n_kernel<T><<<dim3((unsigned)(N / 4), 1, Bz), 256, 0, s>>>(Tm, N, r, n, z, bt.ws, bt.ns);
+  trmv_n_kernel<T><<<dim3((unsigned)(N / 4), 1, Bz), 256, 0, s>>>(Tm, N, r, n, z, bt.ws, bt.ns, (long)n);
   const int chunk = trmv_chunk(N), nchunks = (int)((N + chunk - 1) / chunk);
   dim3 grid((unsigned)(N / 64), (unsigned)nchunks, Bz);
   trmv_t_kernel<T><<<grid, 256, 0, s>>>(Tm, N, z, partials, bt.ws, chunk);
   trmv_t_reduce_kernel<T><<<dim3((unsigned)((N + 255) / 256) + 1, 1, Bz), 256, 0, s>>>(partials, N, nchunks, alpha, bt.ws, chunk,
                                                                                    z, quad);
+  return (int)hipGetLastError();
+}
+
+// ---- iterative refinement of the fp32 solve (dgp_internal.h::refine_solve) ------------------------------------------
+// alpha <- alpha0 + delta (rounded once to T) and quad = sum_i r_i alpha0_i + rho_i (alpha0_i + delta_i) in double: with
+// e = K^^-1 r - alpha0 and K^ e = rho,  r^T K^^-1 r = r^T alpha0 + rho^T alpha0 + rho^T e  exactly, and delta ~ e enters
+// only through rho^T delta -- an error of delta costs |rho| |error|, not |r| |error| as in r^T (alpha0 + delta).
+// One workgroup per site, fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void refine_finish_kernel(T* __restrict__ alpha, const T* __restrict__ delta,
+                                                            const double* __restrict__ rho, const T* __restrict__ r, int n,
+                                                            T* __restrict__ quad, long bs, long ps, long rs,
+                                                            const int* __restrict__ ns) {
+  alpha = site(alpha, bs);
+  quad = site(quad, bs);
+  delta = site(delta, rs);
+  rho = site(rho, ps);
+  r = site(r, (long)n);
+  n = site_n(ns, n);
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const double a0 = (double)alpha[i], a1 = a0 + (double)delta[i];
+    acc += (double)r[i] * a0 + rho[i] * a1;
+    alpha[i] = (T)a1;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    quad[0] = (T)red[0];
+    if (sizeof(T) == 4) *reinterpret_cast<double*>(quad + 3) = red[0];  // the scalar block's unrounded slot (solve())
+  }
+}
+
+template <typename T>
+int refine_solve(const T* Tm, long N, const T* r, int n, const double* rho64, const T* rho32, T* z, T* delta, T* alpha,
+                 T* partials, T* quad, hipStream_t s, Batch bt, long ps, long rs) {
+  const unsigned Bz = (unsigned)bt.B;
+  trmv_n_kernel<T><<<dim3((unsigned)(N / 4), 1, Bz), 256, 0, s>>>(Tm, N, rho32, n, z, bt.ws, bt.ns, rs);
+  const int chunk = trmv_chunk(N), nchunks = (int)((N + chunk - 1) / chunk);
+  dim3 grid((unsigned)(N / 64), (unsigned)nchunks, Bz);
+  trmv_t_kernel<T><<<grid, 256, 0, s>>>(Tm, N, z, partials, bt.ws, chunk);
+  // delta sits in the caller's scratch at site stride rs: the reduce kernel strides its output by `bs`
+  trmv_t_reduce_kernel<T><<<dim3((unsigned)((N + 255) / 256) + 1, 1, Bz), 256, 0, s>>>(partials, N, nchunks, delta, bt.ws, chunk,
+                                                                                   z, nullptr, rs);
+  refine_finish_kernel<T><<<dim3(1, 1, Bz), 256, 0, s>>>(alpha, delta, rho64, r, n, quad, bt.ws, ps, rs, bt.ns);
   return (int)hipGetLastError();
 }
 
@@ -1269,12 +1375,13 @@ int sample_draws(const T* L, long M, const T* Z, long Q, const T* mean, int m, i
   template int potrf<T>(T*, long, T*, T*, int*, int, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, int, \
                         const int*, hipEvent_t*, void (*)(void*, int), void*, Batch, int, PotrfCarry*);                                                                                        \
   template int potrf_split<T>(T*, long, T*, T*, int*, T*, hipStream_t, hipStream_t, hipStream_t, hipEvent_t*, hipEvent_t*, int*, double*, \
-                              int, const int*, hipEvent_t*, void (*)(void*, int), void*, int, int);                       \
+                              int, const int*, hipEvent_t*, void (*)(void*, int), void*, int, int, const Tuning*);         \
   template int potrf_group<T>(T*, long, int, T*, T*, int*, int, int, hipStream_t);                                \
   template int trtri_advance<T>(const T*, long, T*, T*, int, TrtriProgress*, hipStream_t, int, int*, int, int, Batch, long);                   \
   template int trtri<T>(const T*, const T*, long, T*, T*, hipStream_t, Batch, long);                                        \
   template int lauum<T>(const T*, long, T*, hipStream_t, Batch);                                                      \
   template int solve<T>(const T*, long, const T*, int, T*, T*, T*, T*, hipStream_t, Batch);                           \
+  template int refine_solve<T>(const T*, long, const T*, int, const double*, const T*, T*, T*, T*, T*, T*, hipStream_t, Batch, long, long); \
   template int finish<T>(const T*, const T*, long, int, T*, hipStream_t, Batch);                                      \
   template int predict_var<T>(const T*, long, const T*, long, T*, const T*, const T*, T*, T*, T*, hipStream_t, Batch, long);
 DGP_INST(double)

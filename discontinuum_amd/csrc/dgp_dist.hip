@@ -173,8 +173,9 @@ __global__ __launch_bounds__(256, (TileCore<T, false, false, BT, BT>::OCC)) void
   const long k0 = (long)bi * NB;                                           // T[:, bi] starts at its diagonal block
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
-  K::run(Q + (k0 - c0) * GW + (long)jq * BT, GW, Tslab + k0 * Cl + (long)lb * NB + (long)(lq % PER) * BT, Cl,
-         (int)((N - k0) / 16), smem, acc);
+  // k from the last row up to the diagonal block: small-to-large, like the single-GPU lauum_kernel (dgp_gemm.h REV)
+  K::template run<true>(Q + (k0 - c0) * GW + (long)jq * BT, GW, Tslab + k0 * Cl + (long)lb * NB + (long)(lq % PER) * BT, Cl,
+                        (int)((N - k0) / 16), smem, acc);
   T* out = Sslab + col_j * Cl + (long)lb * NB + (long)(lq % PER) * BT;
   G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * Cl + c] = v; });
 }

@@ -120,7 +120,11 @@ struct TileGemm {
 
   // PF = number of k-tiles the global loads run ahead of the MFMAs (register-staged).  PF = 2 costs one more
   // set of staging registers and pays where the operands miss L2 (long, unsynchronised k-ranges: lauum / trtri).
-  template <int PF = 1>
+  // REV: the k-tiles are visited from the LAST to the first (inside a k-tile of 16 the order stays ascending) -- for
+  // products whose terms DECAY along k (K^^-1 = L^-T L^-1: k starts at the diagonal block, where L^-1 is largest): summed
+  // large-to-small in fp32, every late product below half an ulp of the running sum is dropped, a systematic loss
+  // (measured: tr(S K^) - n = -109 at n = 16384, all of the fp32 plans' gradient error); small-to-large keeps them.
+  template <int PF = 1, bool REV = false>
   static __device__ __forceinline__ void run(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb,
                                              int ktiles, T* __restrict__ smem, acc_t (&acc)[MI][NI]) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -128,8 +132,14 @@ struct TileGemm {
     T* sA = smem;
     T* sB = smem + OA::ELEMS;
     ktiles = ktiles * 16 / BK;  // callers count k in tiles of 16; every k-range is a multiple of 128
-    const long stepA = A_KC ? BK : BK * lda;
-    const long stepB = B_KC ? BK : BK * ldb;
+    long stepA = A_KC ? BK : BK * lda;
+    long stepB = B_KC ? BK : BK * ldb;
+    if (REV) {
+      A += (long)(ktiles - 1) * stepA;
+      B += (long)(ktiles - 1) * stepB;
+      stepA = -stepA;
+      stepB = -stepB;
+    }
     T ra[PF][OA::EPT], rb[PF][OB::EPT];
 #pragma unroll
     for (int p = 0; p < PF; ++p)

@@ -93,6 +93,9 @@ struct DmaGemm {
 
   // A, B: (row 0, k 0) of the operand tiles with leading dimensions lda, ldb; ktiles >= 1 counts k in units of 16 (every caller's
   // k-range is a multiple of 128).  acc comes in initialised (zero, or -C for a trailing update).  All 256 threads call it together.
+  // REV: chunks from the last to the first (TileGemm::run's REV: small-to-large summation of products that decay along k; the
+  // order inside a k-tile of 16 stays ascending in both cores, so they remain bitwise equal to each other).
+  template <bool REV = false>
   static __device__ __forceinline__ void run(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int ktiles,
                                              T* __restrict__ smem, acc_t (&acc)[4][4]) {
     const int t = threadIdx.x, lane = t & 63;
@@ -100,7 +103,24 @@ struct DmaGemm {
     const unsigned va = OA::voff(lane, w, lda), vb = OB::voff(lane, w, ldb);
     const char* a = OA::base0(A, w, lda);
     const char* b = OB::base0(B, w, ldb);
-    const long a2 = OA::second(lda), b2 = OB::second(ldb), sa = OA::step(lda), sb = OB::step(ldb);
+    const long a2 = OA::second(lda), b2 = OB::second(ldb);
+    long sa = OA::step(lda), sb = OB::step(ldb);
+    // REV walks the k-TILES of 16 downwards, ascending inside each (TileGemm's order).  fp32: a chunk is a k-tile.  fp64: a
+    // k-tile is two chunks -- start at the first chunk of the last tile and step +1, -3, +1, -3 ... chunks.
+    long sa_odd = sa, sb_odd = sb;  // step after an odd-numbered issue (fp64 REV: back to the previous tile's first chunk)
+    if (REV) {
+      const long first = (long)(ktiles * 16 / KCH) - (F64 ? 2 : 1);
+      a += first * sa;
+      b += first * sb;
+      if (F64) {
+        sa_odd = -3 * sa;
+        sb_odd = -3 * sb;
+      } else {
+        sa = sa_odd = -sa;
+        sb = sb_odd = -sb;
+      }
+    }
+    int issued = 0;
     const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(dgp_lds_ptr)smem);
     const unsigned la = lds + w * OA::LDS0, lb = lds + AREA * (unsigned)sizeof(T) + w * OB::LDS0;
     auto issue = [&](int slot) {
@@ -109,8 +129,14 @@ struct DmaGemm {
       dma(va, a + a2, la + o + OA::LDS1);
       dma(vb, b, lb + o);
       dma(vb, b + b2, lb + o + OB::LDS1);
-      a += sa;
-      b += sb;
+      if (REV && F64) {
+        a += (issued & 1) ? sa_odd : sa;
+        b += (issued & 1) ? sb_odd : sb;
+        ++issued;
+      } else {
+        a += sa;
+        b += sb;
+      }
     };
     int qa[4], qb[4];
     OA::frag_base(lane, (w >> 1) * 64, qa);
@@ -178,10 +204,11 @@ struct TileCore {
   static constexpr bool DMA = ALLOW_DMA && BM == 128 && BN == 128;
   static constexpr int OCC = DMA ? 3 : 2;
   static constexpr int SMEM_ELEMS = DMA ? D::SMEM_ELEMS : G::SMEM_ELEMS;
+  template <bool REV = false>
   static __device__ __forceinline__ void run(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int ktiles,
                                              T* __restrict__ smem, typename G::acc_t (&acc)[G::MI][G::NI]) {
-    if constexpr (DMA) D::run(A, lda, B, ldb, ktiles, smem, acc);
-    else G::template run<PF>(A, lda, B, ldb, ktiles, smem, acc);
+    if constexpr (DMA) D::template run<REV>(A, lda, B, ldb, ktiles, smem, acc);
+    else G::template run<PF, REV>(A, lda, B, ldb, ktiles, smem, acc);
   }
 };
 

@@ -502,6 +502,125 @@ __global__ __launch_bounds__(256) void gram_grad_slab_kernel(const T* __restrict
   if (t < M::NTHETA) partials[blk * DGP_MAX_THETA + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
 
+// ------------------------------------------------------------------------------------------
+// Iterative refinement of fp32 plans (SURVEY.md section 8d's fp32 row; the reference's dtype,
+// src/discontinuum/engines/gpytorch.py:221-222): the residual rho = r - (K + diag(noise)) alpha in DOUBLE.  K^ was
+// overwritten by its factor, so the covariance is re-evaluated from the stored fp32 coordinates with the fp64
+// evaluator M = Model<double> and multiplied into alpha on the fly -- never materialised.  One workgroup per lower
+// 64 x 64 tile (bi >= bj): its row sums go to part[bi][bj][0..63] and, for an off-diagonal tile, its column sums (the
+// transposed tile) to part[bj][bi][..]; the second stage adds a row block's nb partials in block order, so the result
+// does not depend on scheduling.  VALU-bound like gram_sym in fp64 (one pair evaluation per entry of the lower
+// triangle): N(N + 64) / 2 evaluations per site.
+template <typename TS, typename M>
+__device__ __forceinline__ void stage_strip_as_double(const TS* __restrict__ Xt, long N, long base, const typename M::Pre& pre,
+                                                      double (*sf)[64], int lane) {
+  double x[M::NX], f[M::NF];
+#pragma unroll
+  for (int c = 0; c < M::NX; ++c) x[c] = (double)Xt[(long)c * N + base + lane];
+  M::features(x, pre, f);
+#pragma unroll
+  for (int c = 0; c < M::NF; ++c) sf[c][lane] = f[c];
+}
+
+template <typename TS, typename M>
+__global__ __launch_bounds__(256) void gram_matvec_kernel(const TS* __restrict__ Xt, long N, int n, const PreBatch<M> pb,
+                                                          const TS* __restrict__ alpha, double* __restrict__ part, long bs,
+                                                          long ps, const int* __restrict__ ns) {
+  const typename M::Pre& pre = pb.get();
+  Xt = site(Xt, bs);
+  alpha = site(alpha, bs);
+  part = site(part, ps);
+  n = site_n(ns, n);
+  __shared__ double sfi[M::NF][64], sfj[M::NF][64], sai[64], saj[64];
+  __shared__ double racc[16][64], cacc[16][64];
+  int bi, bj;
+  tri_decode(blockIdx.x, bi, bj);
+  const int nb = (int)(N / 64);
+  const int t = threadIdx.x;
+  exp_table_init<double>();
+  if (t < 64) {
+    stage_strip_as_double<TS, M>(Xt, N, (long)bi * 64, pre, sfi, t);
+    const long gi = (long)bi * 64 + t;
+    sai[t] = gi < n ? (double)alpha[gi] : 0.0;  // pad rows / columns contribute nothing
+  } else if (t < 128) {
+    stage_strip_as_double<TS, M>(Xt, N, (long)bj * 64, pre, sfj, t - 64);
+    const long gj = (long)bj * 64 + t - 64;
+    saj[t - 64] = gj < n ? (double)alpha[gj] : 0.0;
+  }
+  __syncthreads();
+  const int ty = t >> 4, tx = t & 15;
+  double fj[4][M::NF], aj[4], cs[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fj[b][c] = sfj[c][tx * 4 + b];
+    aj[b] = saj[tx * 4 + b];
+  }
+  double dummy[M::NTHETA];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    double fi[M::NF];
+#pragma unroll
+    for (int c = 0; c < M::NF; ++c) fi[c] = sfi[c][ty * 4 + a];
+    const double ai = sai[ty * 4 + a];
+    double rsum = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const double v = M::template pair<false>(fi, fj[b], pre, 0.0, dummy);
+      rsum += v * aj[b];
+      cs[b] += v * ai;
+    }
+    racc[tx][ty * 4 + a] = rsum;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) cacc[ty][tx * 4 + b] = cs[b];
+  __syncthreads();
+  if (t < 64) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += racc[k][t];
+    part[((long)bi * nb + bj) * 64 + t] = v;
+  } else if (t < 128 && bi != bj) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += cacc[k][t - 64];
+    part[((long)bj * nb + bi) * 64 + t - 64] = v;
+  }
+}
+
+// rho_i = r_i - noise_i alpha_i - sum_b part[i / 64][b][i % 64]   (i < n; 0 in the pad), as double and rounded to TS
+template <typename TS>
+__global__ __launch_bounds__(256) void resid_reduce_kernel(const double* __restrict__ part, long N, int n,
+                                                           const TS* __restrict__ r, const TS* __restrict__ noise,
+                                                           const TS* __restrict__ alpha, double* __restrict__ rho64,
+                                                           TS* __restrict__ rho32, long bs, long ps, long rs,
+                                                           const int* __restrict__ ns) {
+  part = site(part, ps);
+  rho64 = site(rho64, ps);
+  rho32 = site(rho32, rs);
+  alpha = site(alpha, bs);
+  r = site(r, (long)n);
+  noise = site(noise, (long)n);
+  n = site_n(ns, n);
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int nb = (int)(N / 64);
+  const double* p = part + (i / 64) * (long)nb * 64 + (i & 63);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four fixed interleaved chains (latency), joined in a fixed order
+  int b = 0;
+  for (; b + 4 <= nb; b += 4) {
+    s0 += p[(long)b * 64];
+    s1 += p[(long)(b + 1) * 64];
+    s2 += p[(long)(b + 2) * 64];
+    s3 += p[(long)(b + 3) * 64];
+  }
+  for (; b < nb; ++b) s0 += p[(long)b * 64];
+  double v = 0.0;
+  if (i < n) v = (double)r[i] - (double)noise[i] * (double)alpha[i] - ((s0 + s1) + (s2 + s3));
+  rho64[i] = v;
+  rho32[i] = (TS)v;
+}
+
 // deterministic second stage: one block, fixed summation order
 template <typename T>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const T* __restrict__ partials, long nblk, int nt,
@@ -673,6 +792,32 @@ int gemv_rows(const T* Ks, long N, long Mp, int m, const T* w, T* out, hipStream
   gemv_rows_kernel<T><<<dim3((unsigned)((N + 3) / 4), 1, (unsigned)B), 256, 0, s>>>(Ks, N, Mp, m, w, out, wbs);
   return (int)hipGetLastError();
 }
+
+// scratch per site: part (nb^2 x 64 doubles) | rho64 (N doubles) | rho32 (N TS) | delta (N TS); dgp_api.hip carves it
+// out of the plan's S buffer, which is free between the solves and lauum
+size_t gram_residual_scratch_bytes(long N) {
+  const size_t nb = (size_t)(N / 64);
+  return nb * nb * 64 * sizeof(double) + (size_t)N * sizeof(double) + 2 * (size_t)N * sizeof(float);
+}
+
+template <typename TS>
+int gram_residual(int model, int d, const TS* Xt, long N, int n, const double* theta, const TS* noise, const TS* r,
+                  const TS* alpha, double* part, double* rho64, TS* rho32, hipStream_t s, Batch bt, long ps, long rs,
+                  void* pre_scratch, void* pre_staging) {
+  using T = double;  // the evaluator's arithmetic type (DGP_DISPATCH_MODEL instantiates Model<T, ...>)
+  const int nt = model_ntheta(model, d);
+  if (nt < 0) return -2;
+  const long nb = N / 64;
+  const unsigned grid = (unsigned)(nb * (nb + 1) / 2);
+  DGP_DISPATCH_MODEL(model, d, (gram_matvec_kernel<TS, M><<<dim3(grid, 1, (unsigned)bt.B), dim3(256), 0, s>>>(
+                                   Xt, N, n, prepare_batch<M>(theta, nt, bt.B, pre_scratch, true, s, pre_staging), alpha, part, bt.ws, ps,
+                                   bt.ns)));
+  resid_reduce_kernel<TS><<<dim3((unsigned)((N + 255) / 256), 1, (unsigned)bt.B), dim3(256), 0, s>>>(part, N, n, r, noise, alpha, rho64,
+                                                                                                 rho32, bt.ws, ps, rs, bt.ns);
+  return (int)hipGetLastError();
+}
+template int gram_residual<float>(int, int, const float*, long, int, const double*, const float*, const float*, const float*,
+                                  double*, double*, float*, hipStream_t, Batch, long, long, void*, void*);
 
 #define DGP_INST(T)                                                                                              \
   template int pack_x<T>(const T*, int, int, long, T*, hipStream_t, Batch);                                      \

@@ -14,10 +14,22 @@ inline long round_up(long n, long q) { return (n + q - 1) / q * q; }
 // dtype; caller arrays: n or DGP_OUT_LEN).  B = 1 is the plain single-site plan.
 #define DGP_MAX_BATCH_HOST 8     // == DGP_MAX_BATCH in dgp_common.h: hyperparameters by value up to here
 #define DGP_MAX_BATCH_SITES 1024  // largest batch of a plan
+// Tile-shape selectors of the O(n^3) stages.  Plan-level (dgp_plan_set_option) so that a test can force the kernels the
+// benchmark shapes run -- lauum_kernel, the 128-tile rounds of the bulk update, the 128-tile inverse levels -- at sizes
+// the dense oracle reaches; the defaults are the measured optima (environment overrides read once: DGP_LAUUM64,
+// DGP_SYRK_SLOTS, DGP_TRTRI_SMALL).
+struct Tuning {
+  int lauum64_max_tiles;  // K^^-1 = L^-T L^-1 in 64 x 64 tiles while (128-tiles x batch) <= this (1000)
+  int syrk_slots;         // workgroup slots of a bulk-update round: whole rounds in 128 x 128 tiles, the rest cut (512)
+  long trtri_small;       // an inverse level with fewer 128-tiles (x batch) than this runs in 64 x 64 tiles (1024)
+};
+const Tuning& default_tuning();
 struct Batch {
   int B = 1;
   long ws = 0;
   const int* ns = nullptr;  // device array of the sites' own sizes n_b <= n (ragged batch), or null: all n
+  const Tuning* tune = nullptr;  // null: default_tuning()
+  const Tuning& tuning() const { return tune ? *tune : default_tuning(); }
 };
 int model_ntheta(int model, int d);  // number of constrained kernel hyperparameters, -1 if unsupported
 int composite_define(const int* spec, int nspec);  // register a generic composite model (dgp_models.h), -> model id or < 0
@@ -45,6 +57,15 @@ int gram_grad(int model, int d, const T* Xt, long N, int n, const double* theta,
               void* pre_scratch = nullptr, bool pre_ready = false /* gram_sym of this step filled pre_scratch */,
               void* pre_staging = nullptr);
 size_t pre_scratch_bytes(int B);  // device scratch for the hyperparameters of a batch of B (0 up to 8)
+// rho = r - (K(X, X; theta) + diag(noise)) alpha in DOUBLE, the covariance re-evaluated pair by pair from the stored
+// (TS = float) coordinates -- K^ itself was overwritten by its factor.  Lower 64 x 64 tiles only (each tile feeds its
+// row block and, transposed, its column block); `part` = (N/64)^2 x 64 doubles of scratch per site (site stride ps
+// doubles), rho64 / rho32 N elements per site at strides ps / rs.  Deterministic (fixed summation order).
+template <typename TS>
+int gram_residual(int model, int d, const TS* Xt, long N, int n, const double* theta, const TS* noise, const TS* r,
+                  const TS* alpha, double* part, double* rho64, TS* rho32, hipStream_t s, Batch bt, long ps, long rs,
+                  void* pre_scratch, void* pre_staging);
+size_t gram_residual_scratch_bytes(long N);  // part + rho64 + rho32 + delta, per site
 long gram_grad_partials(long N);
 template <typename T>
 int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,
@@ -72,7 +93,7 @@ int potrf_split(T* A, long N, T* Dinv, T* logdet, int* info, T* snap, hipStream_
                 hipEvent_t* ev, hipEvent_t* syrk_ev, int* n_syrk, double* syrk_flop, int nck = 0,
                 const int* ck_blocks = nullptr, hipEvent_t* ck_ev = nullptr, void (*on_ck)(void* ctx, int idx) = nullptr,
                 void* ck_ctx = nullptr, int k_start = 0 /* block columns before it by the single-stream group schedule */,
-                int G_old = 2 /* panels per group of that schedule */);
+                int G_old = 2 /* panels per group of that schedule */, const Tuning* tune = nullptr);
 // progress of the level recursion of trtri when it is issued piecewise (trtri_advance)
 struct TrtriProgress {
   static constexpr int MAXLVL = 16;
@@ -101,6 +122,13 @@ int solve(const T* Tm, long N, const T* r, int n, T* z, T* alpha, T* partials, T
           Batch bt = Batch());
 template <typename T>
 int finish(const T* S, const T* alpha, long N, int n, T* dnoise, hipStream_t s, Batch bt = Batch());
+// fp32 plans, after solve(): one step of iterative refinement with an fp64 residual (dgp_gram.hip::gram_residual).
+//   delta = T^T (T rho32)  (the fp32 factor),  alpha <- alpha + delta,  quad = r^T alpha0 + rho^T (alpha0 + delta) in double
+// (second-order accurate in the error of delta).  z and `partials` are solve()'s scratch; rho32 / delta: N elements each.
+template <typename T>
+int refine_solve(const T* Tm, long N, const T* r, int n, const double* rho64, const T* rho32, T* z, T* delta, T* alpha,
+                 T* partials, T* quad, hipStream_t s, Batch bt, long scratch_stride /* site stride of rho64 (in doubles) */,
+                 long rho32_stride /* site stride of rho32 / delta, in elements */);
 // row slabs of the prediction's column reductions (part: 2 x PREDICT_SPLIT x M elements of workspace)
 #define PREDICT_SPLIT 32
 template <typename T>

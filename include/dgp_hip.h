@@ -42,7 +42,8 @@ extern "C" {
 #define DGP_OUT_NLL 0    /* 1/2 r^T K^^-1 r + 1/2 log|K^| + n/2 log 2 pi */
 #define DGP_OUT_QUAD 1   /* r^T K^^-1 r */
 #define DGP_OUT_LOGDET 2 /* log|K^| */
-#define DGP_OUT_INFO 3   /* 0, or 1-based index of the first non-positive pivot */
+#define DGP_OUT_INFO 3   /* 0, or 1-based index of the first non-positive pivot; -7: an internal wait of the factorisation's
+                            split panel chain timed out (the NLL is NaN; see dgp_chol.hip::chain_wait) */
 #define DGP_OUT_DTHETA 4 /* d NLL / d theta_p, p = 0 .. ntheta-1 */
 #define DGP_OUT_SUM_DR 28 /* sum_i d NLL / d r_i (gradient of a constant prior mean is its negative); fit step only */
 #define DGP_OUT_DR_W0 29  /* sum_i d NLL / d r_i * w0[i], and w1 in the next slot: see dgp_plan_set_dr_weights */
@@ -118,6 +119,28 @@ int dgp_plan_set_dr_weights(dgp_plan* plan, const void* w_dev);
  * one set (a process has few hardware queues), plans driven from different streams get a set each; they live as long
  * as the process.  Results are ordered on the caller's stream whatever the level. */
 int dgp_plan_set_lookahead(dgp_plan* plan, int level);
+/* Plan-level options (any time; they take effect at the next call).  The first three select the TILE SHAPE of the three
+ * O(n^3) stages, which the library otherwise derives from the problem size -- the parity tests use them to run the
+ * kernels of the benchmark shapes (128 x 128 tiles of the direct-to-LDS core) at sizes the dense CPU oracle reaches;
+ * results must not depend on them beyond rounding.  Nothing in the reference corresponds (gpytorch picks its own
+ * LAPACK / CG paths, engines/gpytorch.py:350-353).
+ *   DGP_OPT_LAUUM64_MAX_TILES  K^^-1 = L^-T L^-1 runs in 64 x 64 tiles while (128-tiles x batch) <= value (default 1000;
+ *                              0: always the 128 x 128 kernel)
+ *   DGP_OPT_SYRK_SLOTS         workgroup slots of one round of the bulk trailing update: whole rounds run as 128 x 128
+ *                              tiles, the remainder is cut into 64-wide pieces (default 512)
+ *   DGP_OPT_TRTRI_SMALL        a level of the inverse with fewer than `value` 128-tiles (x batch) runs in 64 x 64 tiles
+ *                              (default 1024; 0: always 128 x 128)
+ *   DGP_OPT_REFINE             float32 plans only (default 1): after the triangular solves, ONE step of iterative
+ *                              refinement -- residual r - K^ alpha in float64 with K^ re-evaluated on the fly, correction
+ *                              through the float32 factor -- so that alpha, the quadratic form and everything computed
+ *                              from alpha (gradients, dnoise, predictive mean) carry ~cond(K^) eps32 SQUARED instead of
+ *                              cond(K^) eps32; the reference trains in float32 (engines/gpytorch.py:221-222). */
+#define DGP_OPT_LAUUM64_MAX_TILES 0
+#define DGP_OPT_SYRK_SLOTS 1
+#define DGP_OPT_TRTRI_SMALL 2
+#define DGP_OPT_REFINE 3
+int dgp_plan_set_option(dgp_plan* plan, int key, int64_t value);
+int dgp_plan_get_option(const dgp_plan* plan, int key, int64_t* value_out);
 int dgp_plan_buffer(const dgp_plan* plan, int which, void** dev_ptr, int64_t* ld);
 
 /* Training inputs X (n x d row-major, device) -> internal SoA copy.  Replaces the train_x tensor
@@ -256,6 +279,18 @@ int dgp_stage_grad(dgp_plan* plan, const double* theta_host, void* dtheta_dev, v
  * work_dev holds the SoA copy of Xs (d * M elements) */
 int dgp_cross_gram(dgp_plan* plan, const double* theta_host, const void* Xs_dev, int64_t m, void* work_dev,
                    void* Ks_dev, void* stream);
+
+/* ---- diagnostics ----
+ * One grid of 128 x 128 output tiles through either tile-GEMM core of the O(n^3) stages (core 0: register-staged
+ * dgp_gemm.h::TileGemm; 1: direct-to-LDS dgp_gemm_dma.h::DmaGemm), for the test that they are BITWISE equal:
+ *     C[128 bm + i][128 bn + j] = sum_{kk < k} opA(128 bm + i, kk) opB(128 bn + j, kk),   bm < tiles_m, bn < tiles_n
+ *     x_kc != 0: op(i, kk) = p[i ld + kk] (k-contiguous);  x_kc == 0: op(i, kk) = p[kk ld + i]
+ * k a multiple of 16; A, B 16-byte aligned with ld a multiple of 16 bytes; all device pointers of `dtype`.
+ * reverse != 0: the k-tiles of 16 are summed from the last to the first (ascending inside a tile) -- the order of
+ * K^^-1 = L^-T L^-1, whose terms decay along k (small-to-large summation; csrc/dgp_gemm.h). */
+int dgp_debug_tile_gemm(int dtype, int core, int a_kc, int b_kc, const void* A_dev, int64_t lda, const void* B_dev,
+                        int64_t ldb, int64_t k, void* C_dev, int64_t ldc, int tiles_m, int tiles_n, int reverse,
+                        void* stream);
 
 #ifdef __cplusplus
 }

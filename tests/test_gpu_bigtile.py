@@ -1,0 +1,136 @@
+"""The kernels that carry the benchmark -- `lauum_kernel`, the 128 x 128 rounds of the bulk `syrk_kernel` and the
+128-tile `trtri_level_kernel`, all on the direct-to-LDS core -- against the DENSE CPU oracle.
+
+By default the library picks them from the problem size (K^^-1 = L^-T L^-1 needs > 1000 tiles x batch, i.e. one site of
+n > 5 700; bulk-update rounds of 512 tiles; inverse levels of >= 1024 tiles), which no dense-oracle test reaches.  The
+plan-level options `DGP_OPT_LAUUM64_MAX_TILES = 0`, `DGP_OPT_SYRK_SLOTS = 4`, `DGP_OPT_TRTRI_SMALL = 0`
+(include/dgp_hip.h) force them on at n = 1000 and n = 1300 (ragged: N = 1408, 11 block columns), where the oracle runs in
+a second: with 4 slots a bulk launch of t tiles has t // 4 whole rounds of 128 x 128 tiles AND a cut remainder.
+
+Tolerances are those of tests/test_gpu_stages.py: fp64 Gram 1e-13 abs, factors 1e-9, NLL 1e-10, gradients / alpha /
+dnoise 1e-8; fp32 (the reference's dtype, src/discontinuum/engines/gpytorch.py:221-222; with the fp64 refinement of
+alpha) NLL 1e-4 max(1, n / 1024), gradients 1e-2.  What the fit step replaces:
+src/discontinuum/engines/gpytorch.py:350-384."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gp_oracle as orc
+from tests.test_gpu_stages import make_case, tril_n
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [("loadest", 3, 1000), ("loadest", 3, 1300), ("rating", 2, 1000), ("rating", 2, 1300)]
+
+
+def force_big_tiles(p):
+    from discontinuum_amd import _lib
+
+    p.set_option(_lib.OPT_LAUUM64_MAX_TILES, 0)
+    p.set_option(_lib.OPT_SYRK_SLOTS, 4)
+    p.set_option(_lib.OPT_TRTRI_SMALL, 0)
+    assert p.get_option(_lib.OPT_LAUUM64_MAX_TILES) == 0 and p.get_option(_lib.OPT_SYRK_SLOTS) == 4
+    assert p.get_option(_lib.OPT_TRTRI_SMALL) == 0
+    return p
+
+
+def forced_plan(model, d, n, X, dtype, dev, lookahead=True, batch=1):
+    from discontinuum_amd.backend import GPPlan
+
+    p = force_big_tiles(GPPlan(model, n, d, dtype=dtype, device=dev, lookahead=lookahead, batch=batch))
+    if batch == 1:
+        p.set_inputs(X.to(dev, dtype).contiguous())
+    return p
+
+
+@pytest.mark.parametrize("model,d,n", SIZES)
+@pytest.mark.parametrize("lookahead", [True, False])
+def test_stages_fp64_on_the_128_tile_kernels(model, d, n, lookahead, gpu_device):
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=1, perturb=0.3)
+    Khat = orc.GRAMS[model](X, X, theta) + torch.diag(noise)
+    p = forced_plan(model, d, n, X, torch.float64, dev, lookahead)
+    p.stage_gram(theta, noise.to(dev))
+    assert (tril_n(p.buffer(_lib.BUF_A), n) - torch.tril(Khat)).abs().max() < 1e-13
+    p.stage_potrf()  # bulk update: whole rounds of 128 x 128 tiles + a cut remainder
+    L_ref = torch.linalg.cholesky(Khat)
+    L = tril_n(p.buffer(_lib.BUF_A), n)
+    assert torch.linalg.norm(L - L_ref) / torch.linalg.norm(L_ref) < 1e-9
+    p.stage_trtri()  # every level in 128 x 128 tiles
+    T = tril_n(p.buffer(_lib.BUF_T), n)
+    eye = torch.eye(n, dtype=torch.float64)
+    assert torch.linalg.norm(T @ L_ref - eye) / np.sqrt(n) < 1e-9
+    p.stage_lauum()  # lauum_kernel
+    S = tril_n(p.buffer(_lib.BUF_S), n)
+    S_full = S + S.T - torch.diag(torch.diagonal(S))
+    assert torch.linalg.norm(S_full @ Khat - eye) / np.sqrt(n) < 1e-7
+    S_ref = torch.cholesky_inverse(L_ref)
+    assert (S - torch.tril(S_ref)).abs().max() / S_ref.abs().max() < 1e-9
+    p.stage_solve(r.to(dev))
+    alpha_ref = torch.cholesky_solve(r[:, None], L_ref)[:, 0]
+    assert (p.buffer(_lib.BUF_ALPHA)[:n].cpu() - alpha_ref).abs().max() / alpha_ref.abs().max() < 1e-8
+    g = p.stage_grad(theta).cpu()
+    _, g_ref, _, _ = orc.nll_data_and_grads(model, X, r, noise, theta)
+    assert (g - g_ref).abs().max() / g_ref.abs().max() < 1e-8
+
+
+@pytest.mark.parametrize("model,d,n", SIZES)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_fit_step_on_the_128_tile_kernels(model, d, n, dtype, gpu_device):
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    X, r, noise, theta = make_case(model, d, n, seed=2, perturb=0.2)
+    val, g_theta, g_r, g_noise = orc.nll_data_and_grads(model, X, r, noise, theta)
+    P = theta.numel()
+    for lookahead in (2, 1, 0):
+        p = forced_plan(model, d, n, X, dtype, dev, lookahead)
+        out, dr, dnoise = p.fit_step(theta, r.to(dev, dtype), noise.to(dev, dtype))
+        out = out.cpu().double()
+        assert out[_lib.OUT_INFO] == 0
+        e_nll = (abs(out[_lib.OUT_NLL] - val) / abs(val)).item()
+        e_g = ((out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + P] - g_theta).abs().max() / g_theta.abs().max()).item()
+        e_a = ((dr.cpu().double() - g_r).abs().max() / g_r.abs().max()).item()
+        e_n = ((dnoise.cpu().double() - g_noise).abs().max() / g_noise.abs().max()).item()
+        if dtype == torch.float64:
+            assert e_nll < 1e-10 and e_g < 1e-8 and e_a < 1e-8 and e_n < 1e-8, (lookahead, e_nll, e_g, e_a, e_n)
+        else:
+            assert e_nll < 1e-4 * max(1.0, n / 1024) and e_g < 1e-2, (lookahead, e_nll, e_g)
+            assert e_a < 1e-2 and e_n < 2e-2, (lookahead, e_a, e_n)
+
+
+@pytest.mark.parametrize("model,d,sizes", [("loadest", 3, [1300, 1000, 1171]), ("rating", 2, [1000, 1300, 640, 1300])])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_ragged_batch_on_the_128_tile_kernels(model, d, sizes, dtype, gpu_device):
+    """A ragged batched plan (gridDim.z = sites; groups of four panels; the group's columns in 128-tiles too) with the
+    128-tile kernels forced on, site by site against the oracle."""
+    from discontinuum_amd import _lib
+
+    dev, B, n = gpu_device, len(sizes), max(sizes)
+    cases = [make_case(model, d, nb, seed=40 + b, perturb=0.2) for b, nb in enumerate(sizes)]
+    X = torch.full((B, n, d), float("nan"), dtype=torch.float64)
+    r = torch.full((B, n), float("nan"), dtype=torch.float64)
+    noise = torch.full((B, n), float("nan"), dtype=torch.float64)
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        X[b, :nb], r[b, :nb], noise[b, :nb] = c[0], c[1], c[2]
+    theta = torch.stack([c[3] for c in cases])
+    pb = forced_plan(model, d, n, None, dtype, dev, lookahead=1, batch=B)
+    pb.set_site_sizes(sizes)
+    pb.set_inputs(X.to(dev, dtype).contiguous())
+    out, dr, dnoise = pb.fit_step(theta, r.to(dev, dtype).contiguous(), noise.to(dev, dtype).contiguous())
+    out = out.cpu().double()
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        val, g_theta, g_r, g_noise = orc.nll_data_and_grads(model, c[0], c[1], c[2], c[3])
+        P = c[3].numel()
+        assert out[b, _lib.OUT_INFO] == 0
+        e_nll = (abs(out[b, _lib.OUT_NLL] - val) / abs(val)).item()
+        e_g = ((out[b, _lib.OUT_DTHETA:_lib.OUT_DTHETA + P] - g_theta).abs().max() / g_theta.abs().max()).item()
+        e_a = ((dr[b, :nb].cpu().double() - g_r).abs().max() / g_r.abs().max()).item()
+        e_n = ((dnoise[b, :nb].cpu().double() - g_noise).abs().max() / g_noise.abs().max()).item()
+        if dtype == torch.float64:
+            assert e_nll < 1e-10 and e_g < 1e-8 and e_a < 1e-8 and e_n < 1e-8, (b, e_nll, e_g, e_a, e_n)
+        else:
+            assert e_nll < 1e-4 * max(1.0, nb / 1024) and e_g < 1e-2 and e_a < 1e-2 and e_n < 2e-2, (b, e_nll, e_g, e_a, e_n)
+        assert bool((dr[b, nb:] == 0).all()) and bool((dnoise[b, nb:] == 0).all())
