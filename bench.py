@@ -12,7 +12,8 @@ batches".  A single fit is bound by the sequential panel chain of its factorisat
 a batch that chain and the launch rate are amortised and the step becomes GEMM-bound.  `value` = fits/s over all
 sites and GPUs; the latency of one site alone on the GPU (a single fit loop, `--sites-per-gpu 1` is the same
 thing as the timed region) is reported next to it (`single_site`).  With N > 1 every rank owns its own sites
-(seeds rank*S .. rank*S+S-1, weak scaling, no data-path collective); the only RCCL traffic is the gather of the
+(global site g = rank + j N lives on rank g mod N -- sites.site_partition -- and is the synthetic site with seed g, which is
+also its row in the gathered table; weak scaling, no data-path collective); the only RCCL traffic is the gather of the
 (NLL, gradient) rows at the end of the timed region.  Rank 0 prints ONE JSON line.
 
 `roofline`     dominant kernel of the step, timed live with HIP events recorded inside the library on the
@@ -20,13 +21,16 @@ thing as the timed region) is reported next to it (`single_site`).  With N > 1 e
                `traffic` comes from the committed rocprofv3 --pmc passes and is emitted only when the sources of
                libdgp_hip.so are the ones those passes were taken on (`source_hash` in the profile JSON).
 `cpu_baseline` the CPU oracle (a dense torch restatement of the reference's gpytorch math -- gpytorch itself is not
-               installable here) on the host cores, rank 0 / N=1 only: the torch thread count is picked by a measured
-               sweep (32 / 64 / 128 / all of the affinity mask, printed), then the median of `--cpu-steps` (5) NLL+gradient
-               steps at n = 8192 fp64, plus the fp32 figure.
+               installable here) on the host cores, rank 0 / N=1 only: the torch thread count is picked by a measured,
+               bracketed two-stage sweep (8 ... all of the affinity mask at n/2, then the best and its neighbours at n;
+               printed), then the median of `--cpu-steps` (3) NLL+gradient steps at n = 8192 fp64,
+               plus the fp32 figure.
 `configs`      (default single-GPU run only) the other BASELINE.json configurations that fit one GPU, each timed here
                with its own rooflines: C1 n~300 engine iterations (both models; warm and cold predict), the engine-level
                `model.fit` iteration at n=8192, C3 rating-gp n=16384 d=2 fp32,
-               C4's per-GPU share (64 sites of n=4096 in one batched plan), C5's matrix on one GPU (n=65536 fp32).
+               C4's per-GPU share (64 sites of n=4096 in one batched plan), C5's matrix on one GPU (n=65536 fp32), and
+               inference from an n=8192 factorisation at the reference workflow's sizes (predict at m=11323, predict_grid,
+               sample(n=1000): posterior covariance + order-11392 Cholesky + draws), each with its MFMA fraction.
 
 `--model rating` runs the headline loop on the rating-gp kernel instead (d = 2); `--config 5` is the torchrun entry
 point of the distributed factorisation + gradient of ONE matrix over all ranks (discontinuum_amd/dist_chol.py).
@@ -98,9 +102,11 @@ def source_hash():
 
 # ------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(n, d, steps):
-    """The oracle (test infrastructure) as the CPU baseline.  torch's intra-op pool is set by MEASUREMENT: one NLL+gradient
-    step at 32 / 64 / 128 / all threads of the affinity mask (those that the mask allows), the fastest setting is kept
-    and the reported value is the median of `steps` steps at it (the sweep's own step counts as one of them)."""
+    """The oracle (test infrastructure) as the CPU baseline.  torch's intra-op pool is set by MEASUREMENT, in two stages so
+    that the minimum is BRACKETED without spending minutes on it: (1) one NLL+gradient step at n/2 (an eighth of the work)
+    for 8 / 16 / 24 / 32 / 48 / 64 / 96 / 128 / all threads of the affinity mask; (2) at the full n, the best count of (1)
+    and its two neighbours in that list, one step each.  The fastest is kept and the reported value is the median of
+    `steps` steps at it (its sweep step counts as one of them)."""
     from oracle import gp_oracle as orc
 
     try:
@@ -120,33 +126,43 @@ def cpu_baseline(n, d, steps):
         return time.perf_counter() - t0
 
     ns = min(n, 8192)
-    p64 = problem(ns, torch.float64)
-    candidates = sorted({c for c in (32, 64, 128, avail) if 1 <= c <= avail} or {avail})
-    torch.set_num_threads(candidates[0])
-    step(p64)  # warm-up (allocator, MKL / OpenBLAS thread pools)
-    sweep = {}
+    candidates = sorted({c for c in (8, 16, 24, 32, 48, 64, 96, 128, avail) if 1 <= c <= avail} or {avail})
+    half = problem(max(256, ns // 2), torch.float64)
+    torch.set_num_threads(candidates[min(3, len(candidates) - 1)])
+    step(half)  # warm-up (allocator, MKL / OpenBLAS thread pools)
+    coarse = {}
     for c in candidates:
+        torch.set_num_threads(c)
+        coarse[c] = step(half)
+    k = candidates.index(min(coarse, key=coarse.get))
+    finalists = candidates[max(0, k - 1):k + 2]
+    p64 = problem(ns, torch.float64)
+    sweep = {}
+    for c in finalists:
         torch.set_num_threads(c)
         sweep[c] = step(p64)
     cores = min(sweep, key=sweep.get)
+    interior = 0 < candidates.index(cores) < len(candidates) - 1 or len(candidates) == 1
     torch.set_num_threads(cores)
     t64 = [sweep[cores]] + [step(p64) for _ in range(max(0, steps - 1))]
     p32 = problem(ns, torch.float32)
-    step(p32)
-    t32 = [step(p32) for _ in range(max(1, min(steps, 3)))]
+    t32 = [step(p32) for _ in range(2)]
     med = statistics.median(t64)
     scale = (ns / n) ** 3
-    sample = (f"median of {len(t64)} NLL+grad steps of oracle/gp_oracle.py (torch CPU fp64 dense, autograd) after 1 warm-up "
-              f"step at n={ns} d={d}: {med:.2f} s (min {min(t64):.2f}, max {max(t64):.2f}); {cores} torch threads -- the fastest "
-              f"of the sweep {{threads: s per step}} = {({c: round(v, 2) for c, v in sweep.items()})} -- of {avail} in the "
-              f"affinity mask, os.cpu_count()={os.cpu_count()}")
+    sample = (f"median of {len(t64)} NLL+grad steps of oracle/gp_oracle.py (torch CPU fp64 dense, autograd) at n={ns} d={d}: "
+              f"{med:.2f} s (min {min(t64):.2f}, max {max(t64):.2f}); {cores} torch threads of {avail} in the affinity mask "
+              f"(os.cpu_count()={os.cpu_count()}), chosen by a two-stage sweep {{threads: s per step}}: at n={half[0].shape[0]} "
+              f"{({c: round(v, 2) for c, v in coarse.items()})}, then at n={ns} {({c: round(v, 2) for c, v in sweep.items()})}; "
+              f"the minimum is {'interior to' if interior else 'at the EDGE of'} the swept counts")
     if ns != n:
         sample += f"; value scaled to n={n} by (n_s/n)^3"
     return {"value": scale / med, "unit": "fits/s", "cores": cores, "kind": "port", "sample": sample,
             "affinity_cores": avail, "steps_s": [round(t, 3) for t in t64],
             "thread_sweep_s": {str(c): round(v, 3) for c, v in sweep.items()},
+            "thread_sweep_half_n_s": {str(c): round(v, 3) for c, v in coarse.items()}, "sweep_minimum_interior": interior,
             "fp32": {"value": scale / statistics.median(t32), "unit": "fits/s", "steps_s": [round(t, 3) for t in t32],
-                     "note": "same restatement in float32 (the reference's dtype, engines/gpytorch.py:221-222)"}}
+                     "note": "same restatement in float32 (the reference's dtype, engines/gpytorch.py:221-222); first step "
+                             "includes the float32 warm-up"}}
 
 
 # ------------------------------------------------------------------------------------------ device-side measurement
@@ -171,6 +187,8 @@ def stage_report(plan, S, dtype_name, level, lib):
     tri_bytes = N * (N + 64) / 2 * esz * S  # lower-triangle 64 x 64 tiles of all sites of the launch
     gram_bytes = tri_bytes + plan.n * plan.d * esz * S
     hbm = lambda b, t: b / (t * 1e-3) / 1e9 if t > 0 else None  # noqa: E731
+    entries = N * (N + 64) / 2 * S
+    slots = VALU_SLOTS.get((plan.model, plan.d, dtype_name), (None, None))
     return {
         "dominant": dom, "achieved": stages[dom]["tflops"], "peak": peak,
         "frac": stages[dom]["tflops"] / peak if stages[dom]["tflops"] else None,
@@ -181,19 +199,69 @@ def stage_report(plan, S, dtype_name, level, lib):
                       "grad": ms[lib.TIME_GRAD]},
         "potrf_stage_tflops": S * N ** 3 / 3.0 / (ms[lib.TIME_POTRF] * 1e-3) / 1e12 if ms[lib.TIME_POTRF] > 0 else None,
         "gram_hbm": {"bound": "hbm", "achieved": hbm(gram_bytes, ms[lib.TIME_GRAM]), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "bytes": gram_bytes, "kernel": "gram_sym_kernel (writes the lower-triangle tiles)"},
+                     "bytes": gram_bytes, "kernel": "gram_sym_kernel (writes the lower-triangle tiles)",
+                     "valu_frac": valu_bound(entries, slots[0], ms[lib.TIME_GRAM]), "valu_slots_per_entry": slots[0]},
         "gram_grad_hbm": {"bound": "hbm", "achieved": hbm(tri_bytes, ms[lib.TIME_GRAD]), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                          "bytes": tri_bytes, "kernel": "gram_grad_kernel + reduction (reads K^^-1 once)"},
+                          "bytes": tri_bytes, "kernel": "gram_grad_kernel + reduction (reads K^^-1 once)",
+                          "valu_frac": valu_bound(entries, slots[1], ms[lib.TIME_GRAD]), "valu_slots_per_entry": slots[1]},
     }
 
 
-def make_plan(model, n, d, dt, dev, S, level, seed0=0):
-    """A (batched) plan with S synthetic sites resident in HBM -> (plan, theta, r, noise) ready for fit_step."""
+def clock_probe(lib, dev, load, load_s, seconds=0.4, nwg=16):
+    """Shader clock (MHz) the chip holds while `load()` -- one asynchronous enqueue of about `load_s` seconds of GPU work
+    on torch's current stream -- runs back to back: `dgp_debug_clock_probe` keeps `nwg` one-wave workgroups resident on a
+    SIDE stream for `seconds` and stamps s_memtime / s_memrealtime at both ends (MI355X_MICROARCH.md "DVFS give-back",
+    item 6: clock = d s_memtime / d s_memrealtime x 100 MHz, median over workgroups).  No product kernel carries a stamp and
+    the probe never runs inside a timed region.  -> {"mhz": median, "min", "max", "workgroups"} or None."""
+    import ctypes as C
+    import math
+
+    try:
+        side = torch.cuda.Stream(device=dev)
+        out = torch.zeros(2 * nwg, dtype=torch.int64, device=dev)
+        reps = max(2, int(math.ceil(1.3 * seconds / max(load_s, 1e-4))))
+        load()  # the chip is already warm from the timed region; one more enqueue so that the probe starts under load
+        rc = lib.dgp_debug_clock_probe(C.c_void_p(out.data_ptr()), nwg, float(seconds), C.c_void_p(side.cuda_stream))
+        if rc != 0:
+            return None
+        for _ in range(reps):
+            load()
+        torch.cuda.synchronize(dev)
+        v = out.cpu().reshape(nwg, 2).double()
+        mhz = sorted((v[:, 0] / v[:, 1] * 100.0).tolist())
+        if not mhz or not all(math.isfinite(x) and x > 0 for x in mhz):
+            return None
+        return {"mhz": round(mhz[len(mhz) // 2], 1), "min": round(mhz[0], 1), "max": round(mhz[-1], 1), "workgroups": nwg,
+                "window_s": seconds, "source": "dgp_debug_clock_probe: d s_memtime / d s_memrealtime x 100 MHz on a side "
+                                               "stream while the load runs back to back (median over workgroups)"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
+NOMINAL_MHZ = 2400.0  # the clock the datasheet peaks are quoted at (MI355X_MICROARCH.md)
+# VALU issue slots per matrix entry of the Gram kernels (ISA counts of the shipped code objects, DESIGN.md section 4):
+# (model, dtype) -> (gram_sym, gram_grad).  One wave-instruction occupies a SIMD's VALU for 4 cycles (64 lanes / 16 per cycle).
+VALU_SLOTS = {("loadest", 3, "f64"): (109, 142)}
+
+
+def valu_bound(entries, slots, ms, clock_mhz=NOMINAL_MHZ):
+    """Fraction of the VALU ISSUE bound a Gram kernel reaches: entries x slots / 64 lanes wave-instructions, 4 cycles each,
+    over 1024 SIMDs at `clock_mhz` -- the roofline that binds these kernels in fp64 (they sit at 0.2-0.3 of HBM)."""
+    if not slots or not ms or ms <= 0:
+        return None
+    bound_s = entries * slots / 64.0 * 4.0 / (1024.0 * clock_mhz * 1e6)
+    return bound_s / (ms * 1e-3)
+
+
+def make_plan(model, n, d, dt, dev, S, level, seed0=0, seed_stride=1):
+    """A (batched) plan with S synthetic sites resident in HBM -> (plan, theta, r, noise) ready for fit_step.  Local site j
+    is the synthetic site with seed seed0 + j seed_stride (multi-GPU runs: rank + j world, the global index of the site in
+    sites.site_partition's round-robin order, which is also the row it gets in the gathered table)."""
     from discontinuum_amd.backend import GPPlan
 
     Xs, rs, nz, th = [], [], [], []
     for sidx in range(S):
-        X, r, noise, theta = site(model, n, d, seed0 + sidx)
+        X, r, noise, theta = site(model, n, d, seed0 + sidx * seed_stride)
         Xs.append(torch.tensor(X, dtype=dt))
         rs.append(torch.tensor(r, dtype=dt))
         nz.append(torch.tensor(noise, dtype=dt))
@@ -206,7 +274,7 @@ def make_plan(model, n, d, dt, dev, S, level, seed0=0):
     return plan, th, rs[0].to(dev).contiguous(), nz[0].to(dev).contiguous()
 
 
-def time_config(name, model, n, d, dtype_name, S, steps, warmup, dev, lib, level=None):
+def time_config(name, model, n, d, dtype_name, S, steps, warmup, dev, lib, level=None, probe=True):
     """One BASELINE configuration on this GPU: `steps` timed fit steps of S sites in one plan."""
     dt = torch.float64 if dtype_name == "f64" else torch.float32
     level = (1 if S > 1 else 2) if level is None else level
@@ -224,12 +292,22 @@ def time_config(name, model, n, d, dtype_name, S, steps, warmup, dev, lib, level
     ok = bool((host[:, lib.OUT_INFO] == 0).all()) and bool(torch.isfinite(host[:, lib.OUT_NLL]).all())
     rep = stage_report(plan, S, dtype_name, level, lib)
     N = plan.N
+    clk = None
+    if probe:  # shader clock while the dominant kernel's stage runs back to back (after the timed steps)
+        if rep["dominant"] == "lauum_kernel":
+            clk = clock_probe(lib.load(), dev, plan.stage_lauum, max(1e-4, rep["stages_ms"]["lauum"] * 1e-3))
+        else:
+            clk = clock_probe(lib.load(), dev, lambda: plan.fit_step(th, r, noise), dtm)
     res = {"workload": name, "kernel": f"{model}-gp", "n": n, "d": d, "dtype": dtype_name, "sites_in_plan": S, "steps": steps,
            "ms_per_step": dtm * 1e3, "fits_per_s": S / dtm, "tflops": S * float(N) ** 3 / dtm / 1e12,
            "frac_of_peak": S * float(N) ** 3 / dtm / 1e12 / PEAK_TFLOPS[dtype_name], "ok": ok,
            "nll_site0": float(host[0, lib.OUT_NLL]), "hbm_gib": plan._ws.numel() / 2 ** 30, "lookahead": level,
            "roofline": {"bound": "mfma", "kernel": rep["dominant"], "achieved": rep["achieved"], "peak": rep["peak"],
-                        "unit": "TFLOP/s", "frac": rep["frac"], "ms_per_step": rep["ms"]},
+                        "unit": "TFLOP/s", "frac": rep["frac"], "ms_per_step": rep["ms"],
+                        "clock_mhz": clk["mhz"] if clk else None,
+                        "frac_at_clock": (rep["achieved"] / (rep["peak"] * clk["mhz"] / NOMINAL_MHZ)) if (clk and rep["achieved"]) else None,
+                        "clock_probed_under": ("the dominant kernel's stage (lauum) back to back" if rep["dominant"] == "lauum_kernel"
+                                               else "whole fit steps back to back") if clk else None},
            "stages_ms": rep["stages_ms"], "stages_tflops": rep["stages_tflops"],
            "gram_hbm_gbs": rep["gram_hbm"]["achieved"], "gram_grad_hbm_gbs": rep["gram_grad_hbm"]["achieved"]}
     del plan
@@ -282,6 +360,73 @@ def engine_iteration(family, n, iters):
                                                     "(plan creation + code objects), predict_ms = warm mean"}
 
 
+def inference_configs(dev, lib, quick):
+    """Inference from ONE n = 8192 loadest factorisation (fp64) at the reference workflow's sizes, through the plan's
+    C-ABI entry points, each piece with its MFMA fraction (flops counted as in DESIGN.md section 4):
+      predict        m = 11323 (a daily grid over a 31-year record: engines/gpytorch.py:460-501, 599-626): K* build,
+                     V = L^-1 K* (n^2 m flop on MFMA), column reductions
+      predict_grid   m = 18 x 384 = 6912 (engines/gpytorch.py:503-549: 18 covariate values x 12 steps a year over the
+                     synthetic record's 32 years)
+      sample         n_draw = 1000 at m = 11323 (engines/gpytorch.py:551-593): posterior covariance K** - V^T V
+                     (n^2 m + m^2 n flop), its Cholesky factor (the same blocked potrf, order 11392: m^3 / 3) and the
+                     draws mean + L z (m^2 n_draw flop)."""
+    from discontinuum_amd.backend import GPPlan
+
+    n, d, dt = 8192, 3, torch.float64
+    peak = PEAK_TFLOPS["f64"]
+    X, r, noise, theta = site("loadest", n, d, 0)
+    plan = GPPlan("loadest", n, d, dtype=dt, device=dev)
+    plan.set_inputs(torch.tensor(X, dtype=dt, device=dev).contiguous())
+    plan.factorize(theta, torch.tensor(r, dtype=dt, device=dev), torch.tensor(noise, dtype=dt, device=dev))
+    rng = np.random.default_rng(1)
+
+    def points(m, grid=None):
+        if grid:
+            t = np.repeat(np.linspace(-16.0, 16.0, grid[0]), grid[1])
+            c1 = np.tile(np.linspace(-2.5, 2.5, grid[1]), grid[0])
+            return torch.tensor(np.stack([t, c1, np.zeros_like(t)], axis=1), dtype=dt, device=dev).contiguous()
+        return torch.tensor(np.concatenate([np.linspace(-16.0, 16.0, m)[:, None], rng.standard_normal((m, d - 1))], axis=1),
+                            dtype=dt, device=dev).contiguous()
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, res
+
+    reps = 2 if quick else 5
+    N = plan.N
+    out = {"factorisation": f"loadest n={n} d={d} fp64, one site (dgp_factorize)", "peak_tflops": peak}
+    for key, m, grid in (("predict_m11323", 11323, None), ("predict_grid_18x384", 6912, (384, 18))):
+        Xs = points(m, grid)
+        ms, (mean, var) = timed(lambda: plan.predict(theta, Xs), reps)
+        fl = float(N) ** 2 * m
+        out[key] = {"m": m, "ms": ms, "flops": fl, "tflops": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / peak,
+                    "ok": bool(torch.isfinite(mean).all() and torch.isfinite(var).all()), "entry": "dgp_predict"}
+    m, ndraw = 11323, 1000
+    Xs = points(m)
+    M = (m + 127) // 128 * 128
+    ms_cov, (mean, cov) = timed(lambda: plan.posterior_cov(theta, Xs), max(1, reps // 2))
+    ms_fac, (Lbuf, jitter) = timed(lambda: plan.psd_safe_factor(cov, m), max(1, reps // 2))
+    ms_draw, draws = timed(lambda: plan.sample_draws(Lbuf, m, mean, ndraw), reps)
+    f_cov, f_fac, f_draw = float(N) ** 2 * M + float(M) ** 2 * N, float(M) ** 3 / 3.0, float(M) ** 2 * ndraw
+    tf = lambda f, t: f / (t * 1e-3) / 1e12  # noqa: E731
+    out["sample_1000_m11323"] = {
+        "m": m, "draws": ndraw, "ms": ms_cov + ms_fac + ms_draw, "jitter": jitter, "ok": bool(torch.isfinite(draws).all()),
+        "posterior_cov": {"ms": ms_cov, "flops": f_cov, "tflops": tf(f_cov, ms_cov), "frac": tf(f_cov, ms_cov) / peak,
+                          "entry": "dgp_posterior_cov"},
+        "factor_order_11392": {"ms": ms_fac, "flops": f_fac, "tflops": tf(f_fac, ms_fac), "frac": tf(f_fac, ms_fac) / peak,
+                               "entry": "dgp_stage_potrf (incl. the copy of the covariance and the info read-back)"},
+        "draws": {"ms": ms_draw, "flops": f_draw, "tflops": tf(f_draw, ms_draw), "frac": tf(f_draw, ms_draw) / peak,
+                  "entry": "dgp_sample_draws (incl. torch.randn of the M x 1024 normals)"}}
+    del plan, cov, Lbuf, draws
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_configs(dev, lib, quick):
     """The BASELINE.json configurations other than the headline that fit one GPU, timed in this run."""
     out = {}
@@ -294,7 +439,9 @@ def run_configs(dev, lib, quick):
                                               "(BASELINE config 4's per-GPU share of 512 sites / 8 GPUs)", "loadest",
                                               4096, 3, "f64", 64, 3 if quick else 8, 2, dev, lib)
     out["C5_matrix_n65536_f32_one_gpu"] = time_config("single n=65536 d=3 fp32 matrix, whole fit step (factor + inverse + "
-                                                      "gradient) on ONE GPU", "loadest", 65536, 3, "f32", 1, 2, 1, dev, lib)
+                                                      "gradient) on ONE GPU", "loadest", 65536, 3, "f32", 1, 2, 1, dev, lib,
+                                                      probe=False)
+    out["inference_from_n8192"] = inference_configs(dev, lib, quick)
     return out
 
 
@@ -362,10 +509,11 @@ def main():
     ap.add_argument("--model", choices=["loadest", "rating"], default="loadest")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=5, help="timed oracle steps of the CPU baseline (after one warm-up)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps of the CPU baseline at the chosen thread count")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (C1, C3, C4 share, C5 on one GPU)")
     ap.add_argument("--quick-configs", action="store_true", help="fewer steps per config (tests)")
     ap.add_argument("--no-lookahead", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the shader-clock probe runs after the timed region")
     ap.add_argument("--sites-per-gpu", type=int, default=32,
                     help="independent sites carried in lockstep by one batched plan per GPU (1.5 GiB of HBM each at "
                          "n = 8192 fp64; 8 -> 104.5, 16 -> 106.7, 32 -> 107.6 fits/s)")
@@ -434,9 +582,9 @@ def main():
     # all S sites (gridDim.z = S), so the sequential panel chain and the launch rate are amortised over them.
     # The single-site plan (latency) uses the default level 2 (early inverse on a third stream).
     level = 0 if args.no_lookahead else (1 if S > 1 else 2)
-    bplan, btheta, ball, bnoise = make_plan(model, n, d, dt, dev, S, level, seed0=rank * S)
+    bplan, btheta, ball, bnoise = make_plan(model, n, d, dt, dev, S, level, seed0=rank, seed_stride=world)
     if S > 1:
-        plan, theta, y0, noise0 = make_plan(model, n, d, dt, dev, 1, 0 if args.no_lookahead else 2, seed0=rank * S)
+        plan, theta, y0, noise0 = make_plan(model, n, d, dt, dev, 1, 0 if args.no_lookahead else 2, seed0=rank)
     else:
         plan, theta, y0, noise0 = bplan, btheta, ball, bnoise
 
@@ -479,6 +627,16 @@ def main():
     assert bool((host[:, _lib.OUT_INFO] == 0).all()) and bool(torch.isfinite(host[:, _lib.OUT_NLL]).all()), "fit step failed"
     assert table.shape[0] == world * S and bool(torch.isfinite(table[:, _lib.OUT_NLL]).all()), "a site failed"
 
+    # ---- shader clock under load, rank 0, AFTER the timed region (the probe shares a few CUs with the load): once while
+    # whole fit steps run back to back, once while the dominant kernel's stage (K^^-1 = L^-T L^-1, lauum_kernel) does
+    clk_step = clk_lauum = None
+    rep = stage_report(bplan, S, args.dtype, level, _lib) if rank == 0 else None  # last step of the TIMED REGION (before any probe)
+    if rank == 0 and not args.no_clock_probe:
+        lauum_s = max(1e-4, rep["stages_ms"]["lauum"] * 1e-3)
+        clk_step = clock_probe(_lib.load(), dev, batch_step, elapsed / args.steps)
+        clk_lauum = clock_probe(_lib.load(), dev, bplan.stage_lauum, lauum_s)
+        torch.cuda.synchronize()
+
     # ---- single-site loop on rank 0: latency of one fit alone on the GPU
     single_ms = None
     if rank == 0:
@@ -493,7 +651,6 @@ def main():
 
     if rank == 0:
         N = bplan.N
-        rep = stage_report(bplan, S, args.dtype, level, _lib)  # last step of the timed region
         dom = rep["dominant"]
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, gfx950 half-count correction applied: scripts/pmc_summary.py); only valid
@@ -512,9 +669,16 @@ def main():
                     traffic_from = f"profiles/{cand} (commit {pmc.get('commit')}, source_hash {shash})"
             except Exception:  # noqa: BLE001
                 traffic = None
+        dom_clk = clk_lauum if dom == "lauum_kernel" else clk_step
         roofline = {
             "bound": "mfma", "kernel": dom, "achieved": rep["achieved"], "peak": rep["peak"], "unit": "TFLOP/s",
             "frac": rep["frac"], "traffic": traffic, "traffic_from": traffic_from,
+            # the clock the chip held under this kernel (in-kernel stamps of a separate probe launch) and the fraction of
+            # the peak AT THAT CLOCK: `frac` mixes pipe utilisation with DVFS, `frac_at_clock` is the utilisation alone
+            "clock_mhz": dom_clk["mhz"] if dom_clk else None,
+            "frac_at_clock": (rep["achieved"] / (rep["peak"] * dom_clk["mhz"] / NOMINAL_MHZ)) if (dom_clk and rep["achieved"]) else None,
+            "clock_probe": {"nominal_mhz": NOMINAL_MHZ, "dominant_kernel_loop": clk_lauum if dom == "lauum_kernel" else None,
+                            "lauum_loop": clk_lauum, "whole_steps": clk_step},
             "launches_per_step": rep["launches"], "ms_per_step": rep["ms"],
             "stages_tflops": rep["stages_tflops"], "stages_ms": rep["stages_ms"],
             "potrf_stage_tflops": rep["potrf_stage_tflops"],

@@ -179,10 +179,15 @@ class GPPlan:
             _lib.check(self.lib.dgp_factorize(self._h, th, _ptr(r), _ptr(noise), _ptr(out), _stream()), "dgp_factorize")
         return out
 
-    def predict(self, theta, Xs: torch.Tensor, chunk: int = 16384):
+    def predict(self, theta, Xs: torch.Tensor, chunk: int | None = None):
         """Latent posterior (K*^T alpha, diag(K** - K*^T K^^-1 K*)) at Xs (m, d) from the held factorisation.
         Batched plans: Xs (batch, m, d), theta (batch, ntheta) -> mean, var (batch, m); every site predicts at its own
-        points from the factorisation the last ``fit_step`` / ``factorize`` left in its slice of the workspace."""
+        points from the factorisation the last ``fit_step`` / ``factorize`` left in its slice of the workspace.
+        ``chunk`` = prediction points per launch sequence.  The work area is batch x 2 N x chunk elements (cross Gram and
+        V = L^-1 K* per site), so the default is 16384 // batch rounded down to a multiple of 128 (at least 128): a
+        batched prediction then needs no more work memory than a single site's (n = 8192 fp64: 2.1 GB)."""
+        if chunk is None:
+            chunk = max(128, (16384 // self.batch) // 128 * 128)
         lead = () if self.batch == 1 else (self.batch,)
         if not (torch.is_tensor(Xs) and Xs.is_cuda and Xs.dtype == self.dtype and Xs.dim() == 2 + len(lead)
                 and Xs.shape[-1] == self.d and tuple(Xs.shape[:-2]) == lead):

@@ -134,10 +134,12 @@ class FitManyState:
     ``weights_only=True`` round-trips ``state.as_dict()``)."""
 
     FIELDS = ("params", "m1", "m2", "step", "lr", "best", "num_bad", "cooldown", "es_best", "stale", "live", "last_obj",
-              "last_iteration", "iterations_done")
+              "last_iteration", "iterations_done", "nan_run")
 
     def __init__(self, **kw):
         for k in self.FIELDS:
+            if k == "nan_run" and k not in kw:  # a state saved before the counter travelled: start it at zero
+                kw[k] = torch.zeros_like(kw["step"], dtype=torch.float64)
             setattr(self, k, kw[k])
 
     def as_dict(self):
@@ -145,7 +147,7 @@ class FitManyState:
 
     @classmethod
     def from_dict(cls, d):
-        return cls(**{k: d[k] for k in cls.FIELDS})
+        return cls(**{k: d[k] for k in cls.FIELDS if k in d})
 
 
 def _per_site_clip(raw_grads: dict, B: int, max_norm: float = 1.0):
@@ -309,6 +311,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
         m2 = {k: v.clone() for k, v in resume.m2.items()}
         step, lr, best, num_bad, cooldown = (getattr(resume, k).clone() for k in ("step", "lr", "best", "num_bad", "cooldown"))
         es_best, stale, live, last_obj = (getattr(resume, k).clone() for k in ("es_best", "stale", "live", "last_obj"))
+        nan_run = resume.nan_run.clone()  # consecutive non-finite objectives: a site 2 bad steps from aborting stays there
         it0 = int(resume.iterations_done)
         last_iteration = torch.where(live, torch.full_like(resume.last_iteration, it0 + iterations - 1), resume.last_iteration)
 
@@ -406,7 +409,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     if return_state:
         state = FitManyState(params={k: v.detach().clone() for k, v in params.items()}, m1=m1, m2=m2, step=step, lr=lr, best=best,
                              num_bad=num_bad, cooldown=cooldown, es_best=es_best, stale=stale, live=live, last_obj=last_obj,
-                             last_iteration=last_iteration, iterations_done=torch.tensor(it0 + iterations))
+                             last_iteration=last_iteration, iterations_done=torch.tensor(it0 + iterations), nan_run=nan_run)
         return last_obj, state
     return last_obj
 

@@ -12,6 +12,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p "$out"
 run() { name=$1; shift; echo "== $name" >> "$out/log.txt"; timeout -k 10 400 "$@" >> "$out/log.txt" 2>&1 || { echo "FAILED: $name" | tee -a "$out/log.txt"; return 1; }; }
 run stats  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --roofline-only --steps 4 || exit 1
+# Counter passes serialise dispatches in queue-ready order: a kernel that polls a word another kernel publishes (the
+# split panel chain of SINGLE-SITE plans, dgp_chol.hip::chain_wait) could be granted before its producer and would then
+# sit out its 2 s time-out.  The profiled command runs the batched plan only, which has no such wait -- the switch is
+# exported anyway so that no counter pass ever depends on that.
+export DGP_SPLIT_CHAIN=0
 run fetch  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 bench.py --roofline-only --steps 3 || exit 1
 run write  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/write" -- python3 bench.py --roofline-only --steps 3 || exit 1
 run mfma   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/mfma" -- python3 bench.py --roofline-only --steps 3 || exit 1
@@ -23,6 +28,7 @@ python3 scripts/chain_timeline.py "$(ls $out/stats/*/*_kernel_trace.csv | head -
 cp "$(ls $out/stats/*/*_kernel_stats.csv | head -1)" "$out/kernel_stats.csv" || ok=0
 cp "$(ls $out/fetch/*/*_counter_collection.csv | head -1)" "$out/fetch_counter_collection.csv" || ok=0
 cp "$(ls $out/write/*/*_counter_collection.csv | head -1)" "$out/write_counter_collection.csv" || ok=0
+cp "$(ls $out/mfma/*/*_counter_collection.csv | head -1)" "$out/mfma_counter_collection.csv" || ok=0
 if [ "$ok" != 1 ]; then echo "a summary step failed: raw rocprofv3 output kept under $out" | tee -a "$out/log.txt"; exit 1; fi
 rm -rf "$out/stats" "$out/fetch" "$out/write" "$out/mfma"
 tail -3 "$out/pmc_hbm.txt"; head -6 "$out/mfma_busy.txt"

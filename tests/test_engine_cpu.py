@@ -526,3 +526,34 @@ def test_bench_gpu_state_sampler_degrades_to_none():
     time.sleep(0.3)
     out = smp.window(t0, time.time())
     assert out is None or out["samples"] >= 1
+
+
+def test_fit_many_state_round_trips_through_weights_only_and_carries_the_nan_counter():
+    """``FitManyState`` is plain tensors: ``torch.save(state.as_dict())`` -> ``torch.load(weights_only=True)`` ->
+    ``from_dict`` gives every field back, including ``nan_run`` (consecutive non-finite objectives per site -- the counter
+    behind the abort of engines/gpytorch.py:356-357, 378-379: a resumed run must not hand a site a fresh budget); a
+    dictionary written before the counter travelled loads with zeros."""
+    import io
+
+    from discontinuum_amd.multisite_fit import FitManyState
+
+    B = 3
+    vec = lambda v: torch.full((B,), float(v), dtype=torch.float64)  # noqa: E731
+    st = FitManyState(params={"a.raw": torch.randn(B, 2, dtype=torch.float64)}, m1={"a.raw": torch.zeros(B, 2, dtype=torch.float64)},
+                      m2={"a.raw": torch.ones(B, 2, dtype=torch.float64)}, step=vec(7), lr=vec(0.1), best=vec(1.5), num_bad=vec(2),
+                      cooldown=vec(0), es_best=vec(1.4), stale=vec(3), live=torch.tensor([True, False, True]), last_obj=vec(1.6),
+                      last_iteration=torch.tensor([6, 4, 6]), iterations_done=torch.tensor(7),
+                      nan_run=torch.tensor([0.0, 2.0, 9.0], dtype=torch.float64))
+    buf = io.BytesIO()
+    torch.save(st.as_dict(), buf)
+    buf.seek(0)
+    back = FitManyState.from_dict(torch.load(buf, weights_only=True))
+    assert set(FitManyState.FIELDS) == set(back.as_dict()) and "nan_run" in FitManyState.FIELDS
+    for k in FitManyState.FIELDS:
+        a, b = getattr(st, k), getattr(back, k)
+        if isinstance(a, dict):
+            assert all(torch.equal(a[q], b[q]) for q in a)
+        else:
+            assert torch.equal(a, b), k
+    old = {k: v for k, v in st.as_dict().items() if k != "nan_run"}
+    assert torch.equal(FitManyState.from_dict(old).nan_run, torch.zeros(B, dtype=torch.float64))

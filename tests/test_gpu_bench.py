@@ -36,6 +36,14 @@ def test_bench_prints_one_contract_line(extra, gpu_device):
     assert len(cpu["steps_s"]) == 2 and cpu["fp32"]["value"] > 0 and cpu["affinity_cores"] >= cpu["cores"]
     assert "configs" not in rec  # only the default n = 8192 run carries the other BASELINE configurations
     assert roof["gram_hbm"]["achieved"] > 0 and roof["gram_grad_hbm"]["achieved"] > 0
+    # the clock-normalised fraction: the shader clock the chip held under the dominant kernel's stage (in-kernel stamps of a
+    # separate probe launch, dgp_debug_clock_probe) and the fraction of the peak at that clock
+    for key in ("clock_mhz", "frac_at_clock", "clock_probe"):
+        assert key in roof, key
+    assert 500 < roof["clock_mhz"] < 3000, roof["clock_mhz"]
+    assert abs(roof["frac_at_clock"] - roof["frac"] * 2400.0 / roof["clock_mhz"]) < 1e-9
+    assert roof["clock_probe"]["whole_steps"]["workgroups"] >= 8
+    assert rec["cpu_baseline"]["sweep_minimum_interior"] in (True, False) and len(rec["cpu_baseline"]["thread_sweep_half_n_s"]) >= 1
     # the box's state during the timed region: null (rocm-smi unavailable / region shorter than a sample) or clock + power
     assert "gpu_state" in rec
     if rec["gpu_state"] is not None:

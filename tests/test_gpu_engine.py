@@ -435,8 +435,9 @@ def test_fit_many_resume_continues_the_run(gpu_device):
     torch.save(st.as_dict(), buf)
     buf.seek(0)
     st2 = FitManyState.from_dict(torch.load(buf, weights_only=True))
-    fb = fit_many(b, data, iterations=15, resume=st2)
-    assert torch.equal(fa, fb)
+    assert torch.equal(st2.nan_run, torch.zeros(len(sizes), dtype=torch.float64))  # the NaN counter travels with the state
+    fb, st3 = fit_many(b, data, iterations=15, resume=st2, return_state=True)
+    assert torch.equal(fa, fb) and int(st3.iterations_done) == 40 and torch.equal(st3.nan_run, st2.nan_run)
     for x, y in zip(a, b):
         px = torch.cat([p.detach().reshape(-1) for p in x.model.parameters()])
         py = torch.cat([p.detach().reshape(-1) for p in y.model.parameters()])

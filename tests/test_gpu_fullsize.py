@@ -83,7 +83,7 @@ def test_config3_rating_fp32_full_size(gpu_device):
     precision the path computes in, tolerances = 4x what was measured (gpurun_out/fullsize_parity.jsonl): the factor
     reproduces K^ on probe vectors (measured 1.5e-6 -> 6e-6), alpha solves K^ alpha = r (residual measured 7.6e-4 -> 3e-3;
     the dense fp64 comparison at n = 4096, where cond(K^) = 3.2e5 is measured, is tests/test_gpu_fp32.py), the NLL
-    pieces agree with the factor (measured 5e-7 -> 2e-6)."""
+    pieces agree with the factor and the returned alpha (measured 3e-6 -> 1e-5)."""
     from discontinuum_amd import _lib
     from discontinuum_amd.backend import GPPlan
 
@@ -116,7 +116,9 @@ def test_config3_rating_fp32_full_size(gpu_device):
     _record(test="config3_rating_n16384_fp32", factor_rel=e_fac, residual_rel=e_res, nll_vs_factor_rel=e_nll)
     assert e_fac < 6e-6, e_fac
     assert e_res < 3e-3, e_res
-    assert e_nll < 2e-6, e_nll
+    # (the row's quadratic form is the refinement's second-order one, r^T alpha0 + rho^T alpha in double -- not r^T of the
+    # fp32-ROUNDED alpha that this check recomputes: they differ by the rounding of alpha, measured 3.1e-6 of the NLL)
+    assert e_nll < 1e-5, e_nll
 
 
 def test_config3_fp32_against_the_fp64_plan(gpu_device):
@@ -181,8 +183,10 @@ def test_config3_fp32_against_the_fp64_plan(gpu_device):
     Kr = pr.buffer(_lib.BUF_A)
     r32 = r.float().double().to(dev)
     e_res_own = (torch.linalg.norm(_sym_matvec(Kr, a32.double()[:, None])[:, 0] - r32) / torch.linalg.norm(r32)).item()
-    _record(test="config3_rating_n16384_fp32_own_system", residual_rel_fp64=e_res_own)
-    assert e_res_own <= 2e-5, e_res_own
+    # its floor is the rounding of alpha itself to fp32: ||K^|| ||alpha|| eps32 / ||r|| (measured: residual 6.0e-5)
+    floor = lmax * torch.linalg.norm(a32.double()).item() * 2.0 ** -24 / torch.linalg.norm(r32).item()
+    _record(test="config3_rating_n16384_fp32_own_system", residual_rel_fp64=e_res_own, alpha_rounding_floor=floor)
+    assert e_res_own <= max(2e-5, 2 * floor), (e_res_own, floor)
     del pr, Kr
     # the same plan without the refinement: the step is what brings the three figures down
     p.set_option(_lib.OPT_REFINE, 0)
