@@ -209,19 +209,20 @@ def stage_report(plan, S, dtype_name, level, lib):
 
 def clock_probe(lib, dev, load, load_s, seconds=0.4, nwg=16):
     """Shader clock (MHz) the chip holds while `load()` -- one asynchronous enqueue of about `load_s` seconds of GPU work
-    on torch's current stream -- runs back to back: `dgp_debug_clock_probe` keeps `nwg` one-wave workgroups resident on a
-    SIDE stream for `seconds` and stamps s_memtime / s_memrealtime at both ends (MI355X_MICROARCH.md "DVFS give-back",
+    on torch's current stream -- runs back to back: `dgp_debug_clock_probe` keeps `nwg` one-wave workgroups resident on
+    one of the library's internal streams for `seconds` and stamps s_memtime / s_memrealtime at both ends (MI355X_MICROARCH.md "DVFS give-back",
     item 6: clock = d s_memtime / d s_memrealtime x 100 MHz, median over workgroups).  No product kernel carries a stamp and
     the probe never runs inside a timed region.  -> {"mhz": median, "min", "max", "workgroups"} or None."""
     import ctypes as C
     import math
 
     try:
-        side = torch.cuda.Stream(device=dev)
         out = torch.zeros(2 * nwg, dtype=torch.int64, device=dev)
         reps = max(2, int(math.ceil(1.3 * seconds / max(load_s, 1e-4))))
         load()  # the chip is already warm from the timed region; one more enqueue so that the probe starts under load
-        rc = lib.dgp_debug_clock_probe(C.c_void_p(out.data_ptr()), nwg, float(seconds), C.c_void_p(side.cuda_stream))
+        # (the probe goes to one of the library's internal streams of the current stream: a stream of its own would take a
+        # hardware queue away from the plans measured after it)
+        rc = lib.dgp_debug_clock_probe(C.c_void_p(out.data_ptr()), nwg, float(seconds), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             return None
         for _ in range(reps):
@@ -232,8 +233,8 @@ def clock_probe(lib, dev, load, load_s, seconds=0.4, nwg=16):
         if not mhz or not all(math.isfinite(x) and x > 0 for x in mhz):
             return None
         return {"mhz": round(mhz[len(mhz) // 2], 1), "min": round(mhz[0], 1), "max": round(mhz[-1], 1), "workgroups": nwg,
-                "window_s": seconds, "source": "dgp_debug_clock_probe: d s_memtime / d s_memrealtime x 100 MHz on a side "
-                                               "stream while the load runs back to back (median over workgroups)"}
+                "window_s": seconds, "source": "dgp_debug_clock_probe: d s_memtime / d s_memrealtime x 100 MHz while the "
+                                               "load runs back to back (median over workgroups)"}
     except Exception:  # noqa: BLE001
         return None
 
@@ -629,12 +630,18 @@ def main():
 
     # ---- shader clock under load, rank 0, AFTER the timed region (the probe shares a few CUs with the load): once while
     # whole fit steps run back to back, once while the dominant kernel's stage (K^^-1 = L^-T L^-1, lauum_kernel) does
-    clk_step = clk_lauum = None
+    clk_step = clk_lauum = clk_potrf = clk_trtri = None
     rep = stage_report(bplan, S, args.dtype, level, _lib) if rank == 0 else None  # last step of the TIMED REGION (before any probe)
     if rank == 0 and not args.no_clock_probe:
         lauum_s = max(1e-4, rep["stages_ms"]["lauum"] * 1e-3)
         clk_step = clock_probe(_lib.load(), dev, batch_step, elapsed / args.steps)
         clk_lauum = clock_probe(_lib.load(), dev, bplan.stage_lauum, lauum_s)
+        # the other two O(n^3) stages in loops of their own (the factorisation needs a fresh K^ each time: Gram + potrf)
+        def potrf_loop():
+            bplan.stage_gram(btheta, bnoise)
+            bplan.stage_potrf()
+        clk_potrf = clock_probe(_lib.load(), dev, potrf_loop, max(1e-4, (rep["stages_ms"]["gram"] + rep["stages_ms"]["potrf_wall"]) * 1e-3))
+        clk_trtri = clock_probe(_lib.load(), dev, bplan.stage_trtri, max(1e-4, rep["stages_ms"]["trtri"] * 1e-3))
         torch.cuda.synchronize()
 
     # ---- single-site loop on rank 0: latency of one fit alone on the GPU
@@ -678,7 +685,12 @@ def main():
             "clock_mhz": dom_clk["mhz"] if dom_clk else None,
             "frac_at_clock": (rep["achieved"] / (rep["peak"] * dom_clk["mhz"] / NOMINAL_MHZ)) if (dom_clk and rep["achieved"]) else None,
             "clock_probe": {"nominal_mhz": NOMINAL_MHZ, "dominant_kernel_loop": clk_lauum if dom == "lauum_kernel" else None,
-                            "lauum_loop": clk_lauum, "whole_steps": clk_step},
+                            "lauum_loop": clk_lauum, "potrf_loop": clk_potrf, "trtri_loop": clk_trtri, "whole_steps": clk_step,
+                            "stages_frac_at_clock": {k: (rep["stages_tflops"][kk] / (rep["peak"] * c["mhz"] / NOMINAL_MHZ)
+                                                         if (c and rep["stages_tflops"].get(kk)) else None)
+                                                     for k, kk, c in (("syrk_kernel (bulk updates, in situ)", "syrk_kernel", clk_potrf),
+                                                                      ("trtri_level_kernel", "trtri_level_kernel", clk_trtri),
+                                                                      ("lauum_kernel", "lauum_kernel", clk_lauum))}},
             "launches_per_step": rep["launches"], "ms_per_step": rep["ms"],
             "stages_tflops": rep["stages_tflops"], "stages_ms": rep["stages_ms"],
             "potrf_stage_tflops": rep["potrf_stage_tflops"],

@@ -384,6 +384,27 @@ static int make_stream(hipStream_t* out, bool high) {
   return e == hipSuccess ? 0 : hipfail(e, "hipStreamCreateWithPriority");
 }
 
+// ---- shader-clock probe ---------------------------------------------------------------------------------------------
+// MI355X lowers its clock under an MFMA-dense load (MI355X_MICROARCH.md "DVFS give-back"), so a kernel's fraction of the
+// 2.4 GHz peak mixes two things: how full it keeps the MFMA pipe and which clock the chip held.  This probe separates
+// them WITHOUT touching a product kernel: a few one-wave workgroups stay resident for `ticks` of the 100 MHz wall clock
+// and stamp the shader-cycle counter (s_memtime) and the wall clock (s_memrealtime) at both ends; the caller runs the
+// load (e.g. back-to-back lauum launches) on another stream meanwhile.  clock = d s_memtime / d s_memrealtime x 100 MHz
+// per workgroup (consecutive workgroup ids land on consecutive XCDs: 8 or more cover every XCD).  The stamps go to a
+// buffer of their own; no product value is computed from them.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out, long long ticks) {
+  const long long r0 = wall_clock64();
+  const long long s0 = clock64();
+  while (wall_clock64() - r0 < ticks) __builtin_amdgcn_s_sleep(64);
+  const long long s1 = clock64();
+  const long long r1 = wall_clock64();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = (unsigned long long)(s1 - s0);
+    out[2 * blockIdx.x + 1] = (unsigned long long)(r1 - r0);
+  }
+}
+
+
 static int ensure_async(dgp_plan* p, hipStream_t s) {
   if (!p->lookahead) return 0;
   // the bulk trailing updates run at the LOWEST priority so that the latency-critical panel chain on
@@ -1095,6 +1116,20 @@ int dgp_cross_gram(dgp_plan* p, const double* theta, const void* Xs, int64_t m, 
   hipStream_t s = (hipStream_t)stream;
   return wrap(DGP_BY_DTYPE(p, cross<double>(p, theta, Xs, m, work, Ks, s), cross<float>(p, theta, Xs, m, work, Ks, s)),
               "dgp_cross_gram");
+}
+
+// The probe runs on the caller-stream's EARLY-INVERSE stream (lowest priority), not on a stream of its own: a process has
+// few hardware queues, and one more stream pushes a later single-site plan's rest / bulk streams into a shared queue
+// (measured: bench.py's single-site loop 12.1 -> 18.5 ms after a probe on a fresh torch stream).  The load runs on
+// `stream` itself (and the library's other internal streams), so the two overlap.
+int dgp_debug_clock_probe(void* out_dev, int nwg, double seconds, void* stream) {
+  if (!out_dev || nwg < 1 || nwg > 1024 || !(seconds > 0.0) || seconds > 5.0) return fail(DGP_E_ARG, "dgp_debug_clock_probe: bad argument");
+  StreamSet* st = stream_set((hipStream_t)stream);
+  if (!st) return fail(DGP_E_ARG, "out of host memory");
+  const int rc = make_stream(&st->early, false);
+  if (rc) return rc;
+  clock_probe_kernel<<<dim3((unsigned)nwg), 64, 0, st->early>>>((unsigned long long*)out_dev, (long long)(seconds * 1e8));
+  return wrap((int)hipGetLastError(), "dgp_debug_clock_probe");
 }
 
 }  // extern "C"

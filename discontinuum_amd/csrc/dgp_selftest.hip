@@ -42,34 +42,7 @@ static int launch(int a_kc, int b_kc, const T* A, long lda, const T* B, long ldb
   return (int)hipGetLastError();
 }
 
-// ---- shader-clock probe ---------------------------------------------------------------------------------------------
-// MI355X lowers its clock under an MFMA-dense load (MI355X_MICROARCH.md "DVFS give-back"), so a kernel's fraction of the
-// 2.4 GHz peak mixes two things: how full it keeps the MFMA pipe and which clock the chip held.  This probe separates
-// them WITHOUT touching a product kernel: a few one-wave workgroups stay resident for `ticks` of the 100 MHz wall clock
-// and stamp the shader-cycle counter (s_memtime) and the wall clock (s_memrealtime) at both ends; the caller runs the
-// load (e.g. back-to-back lauum launches) on another stream meanwhile.  clock = d s_memtime / d s_memrealtime x 100 MHz
-// per workgroup (consecutive workgroup ids land on consecutive XCDs: 8 or more cover every XCD).  The stamps go to a
-// buffer of their own; no product value is computed from them.
-__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out, long long ticks) {
-  const long long r0 = wall_clock64();
-  const long long s0 = clock64();
-  while (wall_clock64() - r0 < ticks) __builtin_amdgcn_s_sleep(64);
-  const long long s1 = clock64();
-  const long long r1 = wall_clock64();
-  if (threadIdx.x == 0) {
-    out[2 * blockIdx.x] = (unsigned long long)(s1 - s0);
-    out[2 * blockIdx.x + 1] = (unsigned long long)(r1 - r0);
-  }
-}
-
 }  // namespace dgp
-
-extern "C" int dgp_debug_clock_probe(void* out_dev, int nwg, double seconds, void* stream) {
-  if (!out_dev || nwg < 1 || nwg > 1024 || !(seconds > 0.0) || seconds > 5.0) return DGP_E_ARG;
-  dgp::clock_probe_kernel<<<dim3((unsigned)nwg), 64, 0, (hipStream_t)stream>>>((unsigned long long*)out_dev,
-                                                                              (long long)(seconds * 1e8));
-  return (int)hipGetLastError();
-}
 
 extern "C" int dgp_debug_tile_gemm(int dtype, int core, int a_kc, int b_kc, const void* A, int64_t lda, const void* B,
                                    int64_t ldb, int64_t k, void* C, int64_t ldc, int tiles_m, int tiles_n, int reverse,

@@ -292,10 +292,11 @@ int dgp_debug_tile_gemm(int dtype, int core, int a_kc, int b_kc, const void* A_d
                         int64_t ldb, int64_t k, void* C_dev, int64_t ldc, int tiles_m, int tiles_n, int reverse,
                         void* stream);
 
-/* Shader-clock probe: `nwg` one-wave workgroups (8 or more reach every XCD) stay resident on `stream` for `seconds`
- * (<= 5) and write (d s_memtime, d s_memrealtime) -- shader cycles and ticks of the 100 MHz wall clock -- to
- * out_dev[2 i], out_dev[2 i + 1] (uint64).  Run the load to be clocked on ANOTHER stream meanwhile: the clock the chip
- * held is d s_memtime / d s_memrealtime x 100 MHz (MI355X lowers it under MFMA-dense load).  bench.py uses it for
+/* Shader-clock probe: `nwg` one-wave workgroups (8 or more reach every XCD) stay resident for `seconds` (<= 5) on one of
+ * the library's INTERNAL streams of the caller's `stream` (no new stream: a process has few hardware queues) and write
+ * (d s_memtime, d s_memrealtime) -- shader cycles and ticks of the 100 MHz wall clock -- to out_dev[2 i], out_dev[2 i + 1]
+ * (uint64).  Enqueue the load to be clocked on `stream` meanwhile and synchronise the DEVICE before reading: the clock the
+ * chip held is d s_memtime / d s_memrealtime x 100 MHz (MI355X lowers it under MFMA-dense load).  bench.py uses it for
  * `roofline.clock_mhz`; no product kernel carries a stamp. */
 int dgp_debug_clock_probe(void* out_dev, int nwg, double seconds, void* stream);
 
