@@ -67,7 +67,10 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   p = __builtin_fma(p, r, 1.0);
   return ldexp(dgp_exp_tab[ni & 63] * p, ni >> 6);
 }
-__device__ __forceinline__ float exp_nonpos(float x) { return exp(x); }
+// float: the hardware transcendental (v_exp_f32 = 2^x, 1 ulp) on x log2(e) -- two instructions where the library expf
+// spends twelve on range reduction, ldexp and special cases that cannot occur for x <= 0 (a result below 2^-126 flushes to
+// 0, which is what it stands for; a NaN stays a NaN).  The argument's rounding costs |x| eps32 relative to a value e^x.
+__device__ __forceinline__ float exp_nonpos(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 __device__ __forceinline__ double sqrt_nonneg(double x) {
   // sqrt of a finite x >= 0 (a scaled squared distance): v_rsq_f64 + two coupled Newton steps, no range scaling
@@ -82,7 +85,7 @@ __device__ __forceinline__ double sqrt_nonneg(double x) {
   d = __builtin_fma(-g, g, x);
   return __builtin_fma(d, h, g);
 }
-__device__ __forceinline__ float sqrt_nonneg(float x) { return sqrt(x); }
+__device__ __forceinline__ float sqrt_nonneg(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, 1 ulp; no denormal rescue
 
 // (sin, cos)(pi t / p) of one point, in double whatever T is: the features carry ~1e-16 (fp64) / 6e-8 (fp32) absolute
 // error, uniformly over all pairs -- the direct fp32 evaluation of sin(pi (t_i - t_j) / p) is only that good near
