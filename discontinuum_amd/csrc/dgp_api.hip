@@ -304,6 +304,11 @@ int dgp_plan_set_option(dgp_plan* p, int key, int64_t value) {
       if (value < 0) return fail(DGP_E_ARG, "dgp_plan_set_option: value out of range");
       p->tune.trtri_small = (long)value;
       return 0;
+    case DGP_OPT_SYRK_ORDER:
+    case DGP_OPT_LAUUM_ORDER:
+      if (value < 0 || value > 64) return fail(DGP_E_ARG, "dgp_plan_set_option: value out of range");
+      (key == DGP_OPT_SYRK_ORDER ? p->tune.syrk_super : p->tune.lauum_super) = (int)value;
+      return 0;
     case DGP_OPT_REFINE:
       if (p->dtype != DGP_F32 && value) return fail(DGP_E_ARG, "dgp_plan_set_option: refinement applies to float32 plans");
       p->refine = value ? 1 : 0;
@@ -319,6 +324,8 @@ int dgp_plan_get_option(const dgp_plan* p, int key, int64_t* value) {
     case DGP_OPT_SYRK_SLOTS: *value = p->tune.syrk_slots; return 0;
     case DGP_OPT_TRTRI_SMALL: *value = p->tune.trtri_small; return 0;
     case DGP_OPT_REFINE: *value = p->refine; return 0;
+    case DGP_OPT_SYRK_ORDER: *value = p->tune.syrk_super; return 0;
+    case DGP_OPT_LAUUM_ORDER: *value = p->tune.lauum_super; return 0;
     default: return fail(DGP_E_ARG, "dgp_plan_get_option: unknown option");
   }
 }

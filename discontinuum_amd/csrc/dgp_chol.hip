@@ -119,18 +119,21 @@ __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int
 
 template <typename T>
 __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg, int nfull,
-                                                                                   int split, long bs) {
+                                                                                   int split, long bs, int nt = 0, int super = 0) {
   A = site(A, bs);
   __shared__ T smem[TileCore<T, true, true>::SMEM_ELEMS];
   const int b = (int)blockIdx.x;
   int bi, bj;
   if (b < nfull) {
-    tri_decode(xcd_remap(b, nfull), bi, bj);  // all tiles cost the same: remap freely
+    // all tiles cost the same: remap freely -- consecutive logical tiles on one XCD; `super` picks the logical order
+    if (super > 0) super_decode(xcd_remap(b, nfull), nt, super, bi, bj);
+    else tri_decode(xcd_remap(b, nfull), bi, bj);
     syrk_tile<T, 128, 128>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem);
     return;
   }
   const int sub = b - nfull;
-  tri_decode(nfull + sub / split, bi, bj);
+  if (super > 0) super_decode(nfull + sub / split, nt, super, bi, bj);
+  else tri_decode(nfull + sub / split, bi, bj);
   const long row0 = (long)(bi + jbeg) * NB, col0 = (long)(bj + jbeg) * NB;
   const int part = sub % split;
   if (split == 2) {
@@ -149,6 +152,8 @@ const Tuning& default_tuning() {
     v.lauum64_max_tiles = getenv("DGP_LAUUM64") ? atoi(getenv("DGP_LAUUM64")) : 1000;
     v.syrk_slots = getenv("DGP_SYRK_SLOTS") ? atoi(getenv("DGP_SYRK_SLOTS")) : 512;
     v.trtri_small = getenv("DGP_TRTRI_SMALL") ? atol(getenv("DGP_TRTRI_SMALL")) : 1024;
+    v.syrk_super = getenv("DGP_SYRK_ORDER") ? atoi(getenv("DGP_SYRK_ORDER")) : 0;
+    v.lauum_super = getenv("DGP_LAUUM_ORDER") ? atoi(getenv("DGP_LAUUM_ORDER")) : 0;
     if (v.syrk_slots < 1) v.syrk_slots = 1;
     return v;
   }();
@@ -294,7 +299,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
         {
           const SyrkShape sh((int)tri(nbk - k - 1), bt.tuning().syrk_slots / bt.B);
-          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s>>>(A, N, k, 1, k + 1, sh.nfull, sh.split, bt.ws);
+          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s>>>(A, N, k, 1, k + 1, sh.nfull, sh.split, bt.ws, nbk - k - 1, bt.tuning().syrk_super);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s);
         flop += tile_flop * tri(nbk - k - 1) * bt.B;
@@ -341,7 +346,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
         {
           const SyrkShape sh((int)tri(nbk - k0 - G), bt.tuning().syrk_slots / bt.B);
-          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s2>>>(A, N, k0 - G, G, k0 + G, sh.nfull, sh.split, bt.ws);
+          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s2>>>(A, N, k0 - G, G, k0 + G, sh.nfull, sh.split, bt.ws, nbk - k0 - G, bt.tuning().syrk_super);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
         flop += (double)G * tile_flop * tri(nbk - k0 - G) * bt.B;
@@ -628,7 +633,7 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
     hipStreamWaitEvent(s2, ER[k], 0);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
     const SyrkShape sh((int)tri(nbk - k - 3), bt.tuning().syrk_slots);
-    syrk_kernel<T><<<dim3(sh.grid, 1, 1), 256, 0, s2>>>(A, N, kfirst, nk, k + 3, sh.nfull, sh.split, 0);
+    syrk_kernel<T><<<dim3(sh.grid, 1, 1), 256, 0, s2>>>(A, N, kfirst, nk, k + 3, sh.nfull, sh.split, 0, nbk - k - 3, bt.tuning().syrk_super);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
     flop += (double)nk * tile_flop * tri(nbk - k - 3);
     ++ns;
@@ -958,14 +963,28 @@ int trtri(const T* L, const T* /*Dinv: already the diagonal blocks of Tm*/, long
 // S[i,j] = sum_{c >= i} T[c,i]^T T[c,j]   (i >= j): K^^-1 = L^-T L^-1
 template <typename T>
 __global__ __launch_bounds__(256, (TileCore<T, false, false>::OCC)) void lauum_kernel(const T* __restrict__ Tm, T* __restrict__ S, long ld,
-                                                                                      int nbk, long bs) {
+                                                                                      int nbk, long bs, int super = 0) {
   Tm = site(Tm, bs);
   S = site(S, bs);
   using K = TileCore<T, false, false, 128, 128, Prefetch<T>::LAUUM>;
   using G = typename K::G;
   __shared__ T smem[K::SMEM_ELEMS];
   int bi, bj;
-  tri_decode(blockIdx.x, bi, bj);  // ascending bi: the long-K tiles are dispatched first
+  if (super > 0) {
+    // EXPERIMENT (Tuning::lauum_super): super x super supertiles, dealt round-robin over the 8 XCDs in row order (long
+    // k-ranges first, every XCD gets the same mix); workgroup b runs on XCD b % 8 and is that XCD's (b / 8)-th tile
+    const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3, s2 = super * super;
+    const int nsr = (nbk + super - 1) / super, st = (j / s2) * 8 + x;
+    if (st >= nsr * (nsr + 1) / 2) return;
+    int R, C;
+    tri_decode(st, R, C);
+    const int l = j % s2;
+    bi = R * super + l / super;
+    bj = C * super + l % super;
+    if (bi >= nbk || bj > bi) return;
+  } else {
+    tri_decode(blockIdx.x, bi, bj);  // ascending bi: the long-K tiles are dispatched first
+  }
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
   const T* base = Tm + (long)bi * NB * ld;
@@ -1003,7 +1022,13 @@ int lauum(const T* Tm, long N, T* S, hipStream_t s, Batch bt) {
     const int nb64 = 2 * nbk;
     lauum64_kernel<T><<<dim3((unsigned)(nb64 * (nb64 + 1) / 2), 1, (unsigned)bt.B), 256, 0, s>>>(Tm, S, N, nb64, bt.ws);
   } else {
-    lauum_kernel<T><<<dim3((unsigned)tiles, 1, (unsigned)bt.B), 256, 0, s>>>(Tm, S, N, nbk, bt.ws);
+    const int sup = bt.tuning().lauum_super;
+    unsigned grid = (unsigned)tiles;
+    if (sup > 0) {
+      const int nsr = (nbk + sup - 1) / sup, nst = nsr * (nsr + 1) / 2;
+      grid = (unsigned)((nst + 7) / 8 * 8 * sup * sup);
+    }
+    lauum_kernel<T><<<dim3(grid, 1, (unsigned)bt.B), 256, 0, s>>>(Tm, S, N, nbk, bt.ws, sup);
   }
   return (int)hipGetLastError();
 }

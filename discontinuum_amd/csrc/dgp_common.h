@@ -82,6 +82,28 @@ __device__ __forceinline__ void tri_decode(int idx, int& bi, int& bj) {
   bj = idx - i * (i + 1) / 2;
 }
 
+// SUPERTILE order of the lower triangle of an nt x nt tile grid: bands of S tile rows, inside a band S x S supertiles
+// left to right (row-major inside each), the band's diagonal supertile (a triangle) last.  A bijection of [0, nt(nt+1)/2)
+// for every nt.  Consecutive indices share S row panels and S column panels instead of one row panel and S^2 column
+// panels: S times less operand traffic beyond L2 when they run on one XCD (xcd_remap).  tri_decode is the case S = 1.
+__device__ __forceinline__ void super_decode(int t, int nt, int S, int& bi, int& bj) {
+  int r0, c0;
+  tri_decode(t, r0, c0);            // r0 = the tile row of t in plain row-major order: tiles above band R = tri(R S) <= t
+  const int R = r0 / S, base = R * S;
+  const int h = min(S, nt - base);  // rows of this band (the last one may be short)
+  const int u = t - base * (base + 1) / 2;
+  if (u < R * h * S) {
+    const int C = u / (h * S), w = u - C * h * S;
+    bi = base + w / S;
+    bj = C * S + w % S;
+  } else {
+    int li, lj;
+    tri_decode(u - R * h * S, li, lj);
+    bi = base + li;
+    bj = base + lj;
+  }
+}
+
 // XCD-aware block remap (cdna_hip_programming.md T1, bijective form): hardware deals consecutive
 // workgroup ids round-robin over the 8 XCDs, each with a private L2.  After the remap the ids that land
 // on one XCD are CONSECUTIVE in the logical tile order, so neighbouring tiles (which share operand

@@ -22,6 +22,8 @@ struct Tuning {
   int lauum64_max_tiles;  // K^^-1 = L^-T L^-1 in 64 x 64 tiles while (128-tiles x batch) <= this (1000)
   int syrk_slots;         // workgroup slots of a bulk-update round: whole rounds in 128 x 128 tiles, the rest cut (512)
   long trtri_small;       // an inverse level with fewer 128-tiles (x batch) than this runs in 64 x 64 tiles (1024)
+  int syrk_super;         // tile order of the bulk update: 0 = rows of the trailing matrix, S > 0 = S x S supertiles (experiment)
+  int lauum_super;        // tile order of K^^-1 = L^-T L^-1: 0 = rows, S > 0 = S x S supertiles dealt round-robin over the XCDs
 };
 const Tuning& default_tuning();
 struct Batch {

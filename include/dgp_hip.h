@@ -139,6 +139,11 @@ int dgp_plan_set_lookahead(dgp_plan* plan, int level);
 #define DGP_OPT_SYRK_SLOTS 1
 #define DGP_OPT_TRTRI_SMALL 2
 #define DGP_OPT_REFINE 3
+/* tile ORDER of the bulk update / of K^^-1 = L^-T L^-1 (measurement knobs, default 0 = rows of the triangle): S > 0 runs
+ * S x S supertiles per XCD -- S times fewer distinct operand panels in flight per L2.  Same tiles, same sums: results are
+ * bitwise those of the default order. */
+#define DGP_OPT_SYRK_ORDER 4
+#define DGP_OPT_LAUUM_ORDER 5
 int dgp_plan_set_option(dgp_plan* plan, int key, int64_t value);
 int dgp_plan_get_option(const dgp_plan* plan, int key, int64_t* value_out);
 int dgp_plan_buffer(const dgp_plan* plan, int which, void** dev_ptr, int64_t* ld);
