@@ -361,6 +361,38 @@ def engine_iteration(family, n, iters):
                                                     "(plan creation + code objects), predict_ms = warm mean"}
 
 
+def split_batch_config(model, n, d, dtype_name, halves, steps, warmup, dev, lib):
+    """The same sites as several batched plans on separate streams (one plan's sequential panel chain runs under the
+    others' bulk updates): ms per sweep of ALL sites and fits/s.  Measured LAST in a run: every extra stream takes one of
+    the process's few hardware queues from whatever is measured after it."""
+    dt = torch.float64 if dtype_name == "f64" else torch.float32
+    plans, seed = [], 0
+    for S in halves:
+        plans.append(make_plan(model, n, d, dt, dev, S, 1, seed0=seed))
+        seed += S
+    streams = [torch.cuda.Stream(device=dev) for _ in halves]
+
+    def sweep():
+        for (plan, th, r, noise), st in zip(plans, streams):
+            with torch.cuda.stream(st):
+                out = plan.fit_step(th, r, noise)[0]
+        return out
+
+    for _ in range(warmup):
+        sweep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = sweep()
+    torch.cuda.synchronize()
+    dtm = (time.perf_counter() - t0) / steps
+    ok = bool(torch.isfinite(out.reshape(-1, lib.OUT_LEN)[:, lib.OUT_NLL]).all())
+    del plans
+    torch.cuda.empty_cache()
+    return {"plans": list(halves), "ms_per_step": dtm * 1e3, "fits_per_s": sum(halves) / dtm, "ok": ok,
+            "note": "several batched plans driven from separate streams, each with its own internal stream set"}
+
+
 def inference_configs(dev, lib, quick):
     """Inference from ONE n = 8192 loadest factorisation (fp64) at the reference workflow's sizes, through the plan's
     C-ABI entry points, each piece with its MFMA fraction (flops counted as in DESIGN.md section 4):
@@ -443,6 +475,10 @@ def run_configs(dev, lib, quick):
                                                       "gradient) on ONE GPU", "loadest", 65536, 3, "f32", 1, 2, 1, dev, lib,
                                                       probe=False)
     out["inference_from_n8192"] = inference_configs(dev, lib, quick)
+    # last (it creates streams): config 4's share as two plans of 32 -- at this size a second plan hides part of the
+    # first one's panel chain (scripts/c4_experiments.py: 82.5 -> 79.9 ms)
+    out["C4_share_64x4096_f64"]["as_two_plans_of_32"] = split_batch_config("loadest", 4096, 3, "f64", (32, 32), 3 if quick else 8, 2,
+                                                                           dev, lib)
     return out
 
 

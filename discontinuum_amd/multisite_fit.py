@@ -168,7 +168,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
              scheduler: bool = True, progress: bool = False, early_stopping: bool = False,
              monotonic_penalty_weight: float = 0.0, grid_size: int = 64, monotonic_penalty_interval: int = 1,
              resume: FitManyState | None = None, return_state: bool = False, generator: torch.Generator | None = None,
-             optimizer: str = "adam", _penalty_uniforms=None):
+             optimizer: str = "adam", penalty_callback=None, penalty_weight: float = 0.0, _penalty_uniforms=None):
     """Fit ``models[i]`` to ``datasets[i] = (covariates, target[, target_unc])`` for all i at once.  Returns the
     per-site final objectives (a float64 tensor) -- with ``return_state=True`` the pair (objectives, ``FitManyState``);
     the models are updated in place (``is_fitted``, parameters, device state).
@@ -179,7 +179,15 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     for all sites through one batched launch sequence.  ``resume``: the state a previous call returned (same sites, same
     order) -- ``iterations`` more iterations from there; ``generator`` seeds the penalty grids.  ``optimizer``: "adam"
     (L2 weight decay 1e-4, the reference's default) or "adamw" (decoupled decay 1e-2), as ``MarginalHIP.fit``
-    (engines/gpytorch.py:268-286); the default learning rate argument applies to both."""
+    (engines/gpytorch.py:268-286); the default learning rate argument applies to both.
+
+    ``penalty_callback`` / ``penalty_weight``: the reference's optional penalty term (engines/gpytorch.py:362-373:
+    ``objective = nll + penalty_weight * penalty_callback()``) for many sites.  The reference's callback is a closure over
+    ONE engine; here the sites' parameters live stacked in this loop, so the callback receives them:
+    ``penalty_callback(site_index, params)`` with ``params`` = {name: that site's raw parameter tensor}, names as in
+    ``models[i].model.named_parameters()`` prefixed with ``model.`` (likelihood parameters: ``likelihood.``), each a
+    differentiable view -- it returns a scalar tensor (anything torch can differentiate w.r.t. those tensors).  Same
+    tolerance as the reference: an exception or a non-tensor result drops the term for that site and iteration."""
     if optimizer not in ("adam", "adamw"):
         raise ValueError(f"Unsupported optimizer: {optimizer!r}. Supported optimizers are 'adam' and 'adamw'.")
     if len(models) != len(datasets) or not models:
@@ -342,6 +350,17 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
             mu = gp_part + prior
             slope = (mu[:, grid_size:] - mu[:, :grid_size]) / FD
             obj = obj + float(monotonic_penalty_weight) * float(interval) * torch.relu(-slope).mean(dim=1)
+        if penalty_callback is not None and penalty_weight > 0.0:
+            pens = []
+            for b in range(B):
+                try:
+                    val = penalty_callback(b, {k: v[b] for k, v in params.items()})
+                    if not torch.is_tensor(val):
+                        val = None
+                except Exception:  # noqa: BLE001 -- the reference swallows callback failures (engines/gpytorch.py:366-370)
+                    val = None
+                pens.append(torch.zeros((), dtype=torch.float64) if val is None else val.reshape(()).to(torch.float64))
+            obj = obj + float(penalty_weight) * torch.stack(pens)
         finite = torch.isfinite(obj.detach())
         ok = finite & live
         nan_run = torch.where(finite | ~live, torch.zeros_like(nan_run), nan_run + 1)

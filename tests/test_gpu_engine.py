@@ -446,6 +446,61 @@ def test_fit_many_resume_continues_the_run(gpu_device):
         fit_many([LoadestGP()], data[:1], iterations=1, resume=st)
 
 
+def test_fit_many_with_an_arbitrary_penalty_callback_follows_model_fit(gpu_device):
+    """The reference's optional penalty term (engines/gpytorch.py:362-373) for many sites at once: a user callback --
+    here a pull of the residual kernel's lengthscales towards 0.5 plus an ordering penalty on two outputscales -- through
+    ``fit_many(penalty_callback=f, penalty_weight=w)`` against ``model.fit(penalty_callback=closure, penalty_weight=w)`` per
+    site (parameters to 1e-6); a callback that raises, or returns a non-tensor, is ignored like the reference ignores it."""
+    import torch.nn.functional as F
+
+    from discontinuum_amd.loadest_gp import LoadestGP
+    from discontinuum_amd.multisite_fit import fit_many
+
+    sizes, iters, w = [70, 96, 64], 30, 0.7
+    data = [loadest_dataset(k, seed=500 + i) for i, k in enumerate(sizes)]
+
+    def penalty(named):  # named: {parameter name (relative to the ExactGP model): raw tensor}
+        ls = F.softplus(named["covar_module.kernels.2.base_kernel.raw_lengthscale"])
+        os0 = F.softplus(named["covar_module.kernels.0.raw_outputscale"])
+        os1 = F.softplus(named["covar_module.kernels.1.raw_outputscale"])
+        return ((ls - 0.5) ** 2).sum() + torch.relu(os1 - os0).sum()
+
+    probe = LoadestGP()
+    probe.fit(*data[0], iterations=1)
+    names = dict(probe.model.named_parameters())
+    assert "covar_module.kernels.2.base_kernel.raw_lengthscale" in names and "covar_module.kernels.0.raw_outputscale" in names
+    solo, plain = [], []
+    for cov, tgt in data:
+        m = LoadestGP()
+        m.fit(cov, tgt, iterations=iters, penalty_callback=lambda m=m: penalty(dict(m.model.named_parameters())), penalty_weight=w)
+        solo.append(m)
+        q = LoadestGP()
+        q.fit(cov, tgt, iterations=iters)
+        plain.append(q)
+    many = [LoadestGP() for _ in sizes]
+    fit_many(many, data, iterations=iters, penalty_weight=w,
+             penalty_callback=lambda b, params: penalty({k[len("model."):]: v for k, v in params.items() if k.startswith("model.")}))
+    for a, b, c in zip(solo, many, plain):
+        pa = torch.cat([p.detach().reshape(-1) for p in a.model.parameters()])
+        pb = torch.cat([p.detach().reshape(-1) for p in b.model.parameters()])
+        pc = torch.cat([p.detach().reshape(-1) for p in c.model.parameters()])
+        assert (pa - pb).abs().max() < 1e-6, (pa - pb).abs().max()
+        assert (pb - pc).abs().max() > 1e-3  # the penalty does steer the fit
+    # failures of the callback are swallowed, like the reference does (the fit is then the plain one)
+
+    def broken(b, params):
+        if b == 1:
+            raise RuntimeError("boom")
+        return 3.0  # not a tensor
+
+    again = [LoadestGP() for _ in sizes]
+    fit_many(again, data, iterations=iters, penalty_callback=broken, penalty_weight=w)
+    for b, c in zip(again, plain):
+        pb = torch.cat([p.detach().reshape(-1) for p in b.model.parameters()])
+        pc = torch.cat([p.detach().reshape(-1) for p in c.model.parameters()])
+        assert (pb - pc).abs().max() < 1e-6
+
+
 def test_fit_many_adamw_follows_the_single_site_trajectories(gpu_device):
     """``fit_many(optimizer="adamw")`` (decoupled weight decay 1e-2) against ``model.fit(optimizer="adamw")`` per site."""
     from discontinuum_amd.loadest_gp import LoadestGP
