@@ -94,7 +94,7 @@ SIGNATURES = {
     "dgp_stage_grad": (_i, [_vp, _dp, _vp, _vp]),
     "dgp_cross_gram": (_i, [_vp, _dp, _vp, _i64, _vp, _vp, _vp]),
     "dgp_debug_clock_probe": (_i, [_vp, _i, C.c_double, _vp]),
-    "dgp_debug_tile_gemm": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _vp]),
+    "dgp_debug_tile_gemm": (_i, [_i, _i, _i, _i, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

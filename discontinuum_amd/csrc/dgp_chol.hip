@@ -743,7 +743,7 @@ int potrf_group(T* A, long ld, int nbk, T* Tinv, T* logdet, int* info, int k0, i
 template <typename T, int STEP, int BT, bool DMA = true>
 __device__ __forceinline__ void trtri_tile(const T* __restrict__ L, T* __restrict__ Tm, T* __restrict__ W, long ld,
                                            int m, int lo, int mid, int hi, int tile, T* __restrict__ smem) {
-  using K = TileCore<T, true, false, BT, BT, Prefetch<T>::TRTRI, DMA>;
+  using K = TileCore<T, true, false, BT, BT, Prefetch<T>::TRTRI, DMA, true>;  // interleaved groups: balanced zero-work skipping
   using G = typename K::G;
   constexpr int KT = BT / 16;  // k-tiles per tile of the reduction dimension
   // A group that the matrix edge cuts off has R = hi - mid < m tile rows: its R m tiles are the FIRST tile indices, so
@@ -757,14 +757,18 @@ __device__ __forceinline__ void trtri_tile(const T* __restrict__ L, T* __restric
   const int j = STEP == 0 ? lo + tile / R : lo + tile % m;
   typename G::acc_t acc[G::MI][G::NI];
   G::zero(acc);
+  // Both products end their k-range in a diagonal block of the triangular T (round 4): the W-step walks k DOWNWARDS from
+  // mid - 1 to j (T[c, j] decays away from the diagonal: small-to-large, and the triangular T[j, j] comes last: columns
+  // jcol > k are structurally zero), the T-step upwards from mid to i (T[i, i] last: rows irow < k are zero).  The
+  // direct-to-LDS core leaves those MFMAs out (TriMode); the register-staged 64-tiles compute them (same results).
   if (STEP == 0) {
-    K::run(L + (long)i * BT * ld + (long)j * BT, ld, Tm + (long)j * BT * ld + (long)j * BT, ld, (mid - j) * KT, smem, acc);
     T* out = W + (long)i * BT * ld + (long)j * BT;
-    G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
+    K::template run_tri<true, TRI_COL_LE>(L + (long)i * BT * ld + (long)j * BT, ld, Tm + (long)j * BT * ld + (long)j * BT, ld, (mid - j) * KT, smem, acc,
+                                          [&]() { K::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; }); });
   } else {
-    K::run(Tm + (long)i * BT * ld + (long)mid * BT, ld, W + (long)mid * BT * ld + (long)j * BT, ld, (i - mid + 1) * KT, smem, acc);
     T* out = Tm + (long)i * BT * ld + (long)j * BT;
-    G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = -v; });
+    K::template run_tri<false, TRI_ROW_GE>(Tm + (long)i * BT * ld + (long)mid * BT, ld, W + (long)mid * BT * ld + (long)j * BT, ld, (i - mid + 1) * KT, smem, acc,
+                                           [&]() { K::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = -v; }); });
   }
 }
 
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(256, (TileCore<T, false, false>::OCC)) void lauum_k
                                                                                       int nbk, long bs, int super = 0) {
   Tm = site(Tm, bs);
   S = site(S, bs);
-  using K = TileCore<T, false, false, 128, 128, Prefetch<T>::LAUUM>;
+  using K = TileCore<T, false, false, 128, 128, Prefetch<T>::LAUUM, true, true>;  // interleaved groups (TriSpec skipping)
   using G = typename K::G;
   __shared__ T smem[K::SMEM_ELEMS];
   int bi, bj;
@@ -991,9 +995,13 @@ __global__ __launch_bounds__(256, (TileCore<T, false, false>::OCC)) void lauum_k
   // k from the LAST row block up to the diagonal block (REV): the rows of L^-1 far below the diagonal hold its smallest
   // entries, and thousands of tiny products added to a sum that already holds the diagonal block's large ones are
   // rounded away in fp32 -- small-to-large keeps them (dgp_gemm.h::run)
-  K::template run<true>(base + (long)bi * NB, ld, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc);
+  // ... and the diagonal block T[bi, bi] comes LAST: rows i > k of it are structurally zero (operand A); of a diagonal tile
+  // only the 16 x 16 sub-tiles on and below the diagonal are needed (the others hold unspecified values: nothing reads S
+  // above its diagonal blocks' diagonal): the direct-to-LDS core leaves those MFMAs out (TriMode, dgp_gemm_dma.h)
   T* out = S + (long)bi * NB * ld + (long)bj * NB;
-  G::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
+  auto store = [&]() { K::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; }); };
+  if (bi == bj) K::template run_tri<true, TRI_LOWER>(base + (long)bi * NB, ld, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc, store);
+  else K::template run_tri<true, TRI_ROW_LE>(base + (long)bi * NB, ld, base + (long)bj * NB, ld, (nbk - bi) * (NB / 16), smem, acc, store);
 }
 
 // the same product in 64 x 64 tiles: four times the workgroups, for matrices whose 128 x 128 tiles do not fill the CUs
@@ -1112,7 +1120,7 @@ __global__ __launch_bounds__(256) void trmv_t_reduce_kernel(const T* __restrict_
   alpha[j] = acc;
 }
 
-// beta = S g for a symmetric matrix stored in its lower triangle (diagonal tiles hold both halves):
+// beta = S g for a symmetric matrix stored in its lower triangle (nothing above the diagonal is read):
 // row part  sum_{j <= i} S[i][j] g_j  +  column part  sum_{i > j} S[i][j] g_i
 template <typename T>
 __global__ __launch_bounds__(256) void symv_row_kernel(const T* __restrict__ S, long ld, const T* __restrict__ g,

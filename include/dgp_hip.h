@@ -292,9 +292,14 @@ int dgp_cross_gram(dgp_plan* plan, const double* theta_host, const void* Xs_dev,
  *     x_kc != 0: op(i, kk) = p[i ld + kk] (k-contiguous);  x_kc == 0: op(i, kk) = p[kk ld + i]
  * k a multiple of 16; A, B 16-byte aligned with ld a multiple of 16 bytes; all device pointers of `dtype`.
  * reverse != 0: the k-tiles of 16 are summed from the last to the first (ascending inside a tile) -- the order of
- * K^^-1 = L^-T L^-1, whose terms decay along k (small-to-large summation; csrc/dgp_gemm.h). */
+ * K^^-1 = L^-T L^-1, whose terms decay along k (small-to-large summation; csrc/dgp_gemm.h).
+ * variant (core 1 only): 0 = the plain accumulator map; 1 = 16-row / 16-column groups dealt alternately to the wave rows /
+ * columns; 2..5 = that map + zero-work skipping in the block of 128 k's visited LAST (k a multiple of 128): 2 operand A is
+ * op(i, kk) = 0 for i > kk there, 3 op(i, kk) = 0 for kk > i, 4 operand B is op(j, kk) = 0 for j > kk, 5 the output is a
+ * diagonal tile of a symmetric product (only the 16 x 16 sub-tiles with row group >= column group are specified).  With
+ * operands that have that structure the specified results are bitwise those of variant 0. */
 int dgp_debug_tile_gemm(int dtype, int core, int a_kc, int b_kc, const void* A_dev, int64_t lda, const void* B_dev,
-                        int64_t ldb, int64_t k, void* C_dev, int64_t ldc, int tiles_m, int tiles_n, int reverse,
+                        int64_t ldb, int64_t k, void* C_dev, int64_t ldc, int tiles_m, int tiles_n, int reverse, int variant,
                         void* stream);
 
 /* Shader-clock probe: `nwg` one-wave workgroups (8 or more reach every XCD) stay resident for `seconds` (<= 5) on one of

@@ -16,13 +16,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _tile_gemm(lib, dtype, core, a_kc, b_kc, A, B, k, tm, tn, reverse=0):
+def _tile_gemm(lib, dtype, core, a_kc, b_kc, A, B, k, tm, tn, reverse=0, variant=0):
     from discontinuum_amd import _lib
 
     Cm = torch.full((128 * tm, 128 * tn), float("nan"), dtype=dtype, device=A.device)
     rc = lib.dgp_debug_tile_gemm(_lib.F64 if dtype == torch.float64 else _lib.F32, core, int(a_kc), int(b_kc),
                                  C.c_void_p(A.data_ptr()), A.stride(0), C.c_void_p(B.data_ptr()), B.stride(0), k,
-                                 C.c_void_p(Cm.data_ptr()), Cm.stride(0), tm, tn, reverse,
+                                 C.c_void_p(Cm.data_ptr()), Cm.stride(0), tm, tn, reverse, variant,
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
     return Cm
@@ -68,7 +68,60 @@ def test_tile_gemm_rejects_bad_arguments(gpu_device):
     A = torch.zeros(128, 24, dtype=torch.float64, device=gpu_device)
     Cm = torch.zeros(128, 128, dtype=torch.float64, device=gpu_device)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    assert lib.dgp_debug_tile_gemm(0, 1, 1, 1, p(A), 24, p(A), 24, 20, p(Cm), 128, 1, 1, 0, None) == -1   # k % 16
-    assert lib.dgp_debug_tile_gemm(0, 1, 1, 1, p(A), 23, p(A), 24, 16, p(Cm), 128, 1, 1, 0, None) == -1   # ld not 16-byte
-    assert lib.dgp_debug_tile_gemm(0, 2, 1, 1, p(A), 24, p(A), 24, 16, p(Cm), 128, 1, 1, 0, None) == -1   # core
-    assert lib.dgp_debug_tile_gemm(0, 1, 1, 1, p(A), 24, p(A), 24, 16, p(Cm), 64, 1, 1, 0, None) == -1    # ldc
+    assert lib.dgp_debug_tile_gemm(0, 1, 1, 1, p(A), 24, p(A), 24, 20, p(Cm), 128, 1, 1, 0, 0, None) == -1   # k % 16
+    assert lib.dgp_debug_tile_gemm(0, 1, 1, 1, p(A), 23, p(A), 24, 16, p(Cm), 128, 1, 1, 0, 0, None) == -1   # ld not 16-byte
+    assert lib.dgp_debug_tile_gemm(0, 2, 1, 1, p(A), 24, p(A), 24, 16, p(Cm), 128, 1, 1, 0, 0, None) == -1   # core
+    assert lib.dgp_debug_tile_gemm(0, 1, 1, 1, p(A), 24, p(A), 24, 16, p(Cm), 64, 1, 1, 0, 0, None) == -1    # ldc
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("k", [128, 256, 384, 512, 640, 1024, 2048])
+def test_interleaved_map_and_zero_work_skipping_are_bitwise_the_plain_core(dtype, k, gpu_device):
+    """The direct-to-LDS core with its 16-row / 16-column groups dealt alternately to the wave rows / columns (variant 1), and
+    on top of that map the zero-work skipping of `lauum_kernel` / `trtri_level_kernel` (variants 2..5: the last block of 128
+    k's unrolled with a compile-time live set per quarter, csrc/dgp_gemm_dma.h) -- on operands that HAVE the triangular
+    structure each mode assumes in the block of 128 k's visited last, in the operand layouts and k directions those kernels
+    use, for k-ranges whose length before that block is 0, 1 and 2 mod 3 chunks (the peeled start of the ring).  Everything
+    computed must be bitwise the plain core's (variant 0): the skipped products are exact zeros."""
+    from discontinuum_amd import _lib
+
+    lib = _lib.load()
+    tm = tn = 2
+    g = torch.Generator().manual_seed(7 + k)
+    rnd = lambda *shape: torch.randn(*shape, dtype=torch.float64, generator=g)  # noqa: E731
+    tri = torch.tril(torch.ones(128, 128, dtype=torch.float64))
+
+    def run(variant, a_kc, b_kc, opA, opB, reverse):  # opA, opB: (rows, k) dense
+        A = (opA if a_kc else opA.T).contiguous().to(dtype).to(gpu_device)
+        B = (opB if b_kc else opB.T).contiguous().to(dtype).to(gpu_device)
+        return _tile_gemm(lib, dtype, 1, a_kc, b_kc, A, B, k, tm, tn, reverse, variant)
+
+    # (variant, a_kc, b_kc, reverse, which operand is triangular in the last-visited block, how)
+    cases = [
+        (2, False, False, 1, "A", "le"),   # lauum: A = T[:, bi] read transposed, k downwards, op(i, kk) = 0 for i > kk in block 0
+        (4, True, False, 1, "B", "le"),    # inverse W-step: B = T[:, j] read transposed, k downwards
+        (3, True, False, 0, "A", "ge"),    # inverse T-step: A = T[i, :] by rows, k upwards, op(i, kk) = 0 for kk > i in the last block
+    ]
+    for variant, a_kc, b_kc, reverse, which, how in cases:
+        opA, opB = rnd(128 * tm, k), rnd(128 * tn, k)
+        blk = slice(0, 128) if reverse else slice(k - 128, k)  # the block of k's visited last
+        mask = tri.T if how == "le" else tri                  # op(i, kk): zero for i > kk  /  zero for kk > i
+        if which == "A":
+            for t in range(tm):
+                opA[128 * t:128 * t + 128, blk] *= mask
+        else:
+            for t in range(tn):
+                opB[128 * t:128 * t + 128, blk] *= mask
+        ref = run(0, a_kc, b_kc, opA, opB, reverse)
+        il = run(1, a_kc, b_kc, opA, opB, reverse)
+        sk = run(variant, a_kc, b_kc, opA, opB, reverse)
+        assert torch.equal(ref, il), (variant, (ref - il).abs().max().item())
+        assert torch.equal(ref, sk), (variant, (ref - sk).abs().max().item())
+    # variant 5: a diagonal tile of a symmetric product -- sub-tiles with row group >= column group only
+    opA = rnd(128 * tm, k)
+    ref = run(0, False, False, opA, opA, 1)
+    low = run(5, False, False, opA, opA, 1)
+    keep = torch.kron(torch.tril(torch.ones(8, 8)), torch.ones(16, 16)).bool().to(gpu_device)
+    for t in range(tm):
+        r_, l_ = ref[128 * t:128 * t + 128, 128 * t:128 * t + 128], low[128 * t:128 * t + 128, 128 * t:128 * t + 128]
+        assert torch.equal(r_[keep], l_[keep])  # (the other sub-tiles are unspecified: zero, or the product)
