@@ -183,6 +183,7 @@ struct TileGemm {
 //         sign on every matrix tried), and the rest contributes K roundings at |C| per pass instead of one.
 // fp32 keeps C in registers from the start of the tile (the loads fly under the first operand loads, as they do in
 // the fp64 form) and subtracts the finished sum from it in the epilogue: `keep` has the accumulators' shape.
+// G = the tile map the accumulators follow: a TileGemm, or a TileCore (whose map may be the interleaved one, dgp_gemm_dma.h).
 // LATE (fp32 only): C is read in the epilogue instead -- the direct-to-LDS core runs at 168 registers per lane, where a
 // second accumulator-sized array only survives the k-loop in scratch memory (measured: bulk update 109 -> 101 TFLOP/s).
 template <typename T, typename G, bool LATE = false>

@@ -228,7 +228,7 @@ struct DmaGemm {
     // loop -- while the accumulators are still the constants they were initialised with, so the branches around the peeled
     // steps merge nothing live -- and the ring starts ROTATED (chunk c in slot (c + 3 - PRE) % 3), so that the steady loop and
     // the unrolled tail both see compile-time slots: ONE tail variant, no bubble.
-    const int pre = TRI == TRI_NONE ? 0 : (C - TB) % SLOTS;
+    const int pre = (TRI == TRI_NONE || TRI == TRI_LOWER) ? 0 : (C - TB) % SLOTS;
     const int p0 = pre == 0 ? 0 : SLOTS - pre;  // slot of chunk 0
     __syncthreads();                  // an earlier use of the ring by this workgroup is over
     issue(p0);
@@ -238,13 +238,19 @@ struct DmaGemm {
     else if (C > 1) wait_vm<4>();
     else wait_vm<0>();
     __syncthreads();  // chunk 0 is complete
-    if constexpr (TRI == TRI_NONE) {
+    if constexpr (TRI == TRI_NONE || TRI == TRI_LOWER) {
+      // (TRI_LOWER: every chunk has the same compile-time live set -- the plain loops with that chunk; nothing to peel, so it
+      // also serves trailing updates, whose accumulators are live from the start)
+      auto chunk_u = [&](int slot) {
+        if constexpr (TRI == TRI_LOWER) chunk_q(slot, std::integral_constant<int, -1>());
+        else chunk(slot);
+      };
       frags(0, 0);
       int c0 = 0;
       for (; c0 + 2 * SLOTS <= C; c0 += SLOTS) {  // steady state, branch-free: every chunk of the round has a chunk SLOTS ahead
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
-          chunk(u);
+          chunk_u(u);
           wait_vm<4 * (SLOTS - 2)>();  // this wave's part of chunk c + 1 has landed (chunk c + 2 may be in flight)
           __syncthreads();             // ... everyone's has; and everyone has chunk c in registers or behind it
           issue(u);                    // chunk c + SLOTS into the slot of chunk c
@@ -255,13 +261,14 @@ struct DmaGemm {
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
           const int c = c0 + u;
-          if (c < C) chunk(u);
+          if (c < C) chunk_u(u);
           wait_vm<0>();
           __syncthreads();
           if (c + SLOTS < C) issue(u);
           if (c + 1 < C) frags((u + 1) % SLOTS, 0);
         }
       }
+      epi();
     } else {
       static_assert(SLOTS == 3, "the peeled start assumes a ring of three");
       auto step = [&](auto uc, auto qc) {  // one chunk in its steady-state form (a chunk SLOTS ahead exists)
@@ -318,6 +325,9 @@ struct TileCore {
   static constexpr bool DMA = ALLOW_DMA && BM == 128 && BN == 128;
   static constexpr bool IL = IL_ && DMA;
   using D = DmaGemm<T, A_KC, B_KC, 3, IL>;
+  using acc_t = typename G::acc_t;  // (the members trailing_begin / trailing_end need of a tile map: dgp_gemm.h)
+  static constexpr int MI = G::MI, NI = G::NI;
+  static __device__ __forceinline__ void zero(acc_t (&acc)[MI][NI]) { G::zero(acc); }
   static constexpr int OCC = DMA ? 3 : 2;
   static constexpr int SMEM_ELEMS = DMA ? D::SMEM_ELEMS : G::SMEM_ELEMS;
   template <bool REV = false>
