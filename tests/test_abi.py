@@ -45,6 +45,37 @@ def test_queries_and_argument_validation_without_a_device():
     assert lib.dgp_plan_destroy(h) == 0
 
 
+def test_plan_options_without_a_device():
+    """dgp_plan_set_option / dgp_plan_get_option are host-side bookkeeping: defaults, round trips, range checks, the
+    float32-only refinement switch, unknown keys; and the diagnostic entry points reject bad arguments before any launch."""
+    lib = _lib.load()
+    h64, h32 = C.c_void_p(), C.c_void_p()
+    assert lib.dgp_plan_create(_lib.MODEL_LOADEST, _lib.F64, 1000, 3, C.byref(h64)) == 0
+    assert lib.dgp_plan_create(_lib.MODEL_RATING, _lib.F32, 1000, 2, C.byref(h32)) == 0
+    v = C.c_int64()
+
+    def get(h, key):
+        assert lib.dgp_plan_get_option(h, key, C.byref(v)) == 0
+        return v.value
+
+    if not any(os.environ.get(k) for k in ("DGP_LAUUM64", "DGP_SYRK_SLOTS", "DGP_TRTRI_SMALL", "DGP_SYRK_ORDER", "DGP_LAUUM_ORDER", "DGP_NO_REFINE")):
+        assert [get(h64, k) for k in range(6)] == [1000, 512, 1024, 0, 0, 0]  # refinement off for float64 plans
+        assert get(h32, _lib.OPT_REFINE) == 1
+    for key, val in ((_lib.OPT_LAUUM64_MAX_TILES, 0), (_lib.OPT_SYRK_SLOTS, 4), (_lib.OPT_TRTRI_SMALL, 0), (_lib.OPT_SYRK_ORDER, 8),
+                     (_lib.OPT_LAUUM_ORDER, 4)):
+        assert lib.dgp_plan_set_option(h64, key, val) == 0 and get(h64, key) == val
+    assert lib.dgp_plan_set_option(h32, _lib.OPT_REFINE, 0) == 0 and get(h32, _lib.OPT_REFINE) == 0
+    assert lib.dgp_plan_set_option(h64, _lib.OPT_REFINE, 1) == -1 and b"float32" in lib.dgp_last_error()
+    assert lib.dgp_plan_set_option(h64, _lib.OPT_REFINE, 0) == 0
+    assert lib.dgp_plan_set_option(h64, _lib.OPT_SYRK_SLOTS, 0) == -1
+    assert lib.dgp_plan_set_option(h64, _lib.OPT_LAUUM_ORDER, 65) == -1
+    assert lib.dgp_plan_set_option(h64, 99, 1) == -1 and lib.dgp_plan_get_option(h64, 99, C.byref(v)) == -1
+    assert lib.dgp_plan_set_option(None, 0, 1) == -1
+    assert lib.dgp_debug_clock_probe(None, 16, 0.1, None) == -1
+    assert lib.dgp_debug_tile_gemm(0, 1, 1, 1, None, 16, None, 16, 128, None, 128, 1, 1, 0, 0, None) == -1
+    assert lib.dgp_plan_destroy(h64) == 0 and lib.dgp_plan_destroy(h32) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
