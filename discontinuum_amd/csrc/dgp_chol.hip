@@ -38,7 +38,10 @@ struct Prefetch {
 // That is only safe while the producer gets dispatched beside the waiter -- true for the hardware queues of distinct
 // streams, NOT for a tool that serialises dispatches in queue-ready order (rocprofv3 --pmc does: a waiter granted first
 // would spin forever; counter passes on single-site plans must run with DGP_SPLIT_CHAIN=0, scripts/collect_profiles.sh
-// exports it) and not after a failed producer launch (checked on the host before the waiter is enqueued).  So every wait
+// exports it), not after a failed producer launch (checked on the host before the waiter is enqueued), and not when the
+// waiters alone can fill the machine: ONE site's trsm / crit launches are at most a few hundred workgroups; a 32-site
+// batch's are thousands, and a GPU full of polling workgroups leaves the producer no slot (measured: every wait ran into its
+// bound, profiles/r04_experiments_batched_split.txt) -- batched plans never poll (split_applies: B == 1).  So every wait
 // is BOUNDED: after CHAIN_WAIT_TICKS of the 100 MHz wall clock (2 s -- a whole n = 8192 fit takes 12 ms) the waiter
 // writes DGP_INFO_CHAIN_TIMEOUT into info[0] and its workgroup returns without touching the matrix; every later waiter
 // sees the code and returns at once, so the chain drains in about one budget, the result row carries info < 0 and a NaN
