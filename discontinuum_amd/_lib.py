@@ -69,6 +69,7 @@ SIGNATURES = {
     "dgp_dist_status": (_i, [_vp, _vp, _vp]),
     "dgp_dist_solve_partial": (_i, [_vp, _vp, _vp, _vp]),
     "dgp_dist_alpha_partial": (_i, [_vp, _vp, _vp, _vp]),
+    "dgp_dist_residual": (_i, [_vp, _dp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_dist_pack_inverse": (_i, [_vp, _i, _vp, _vp]),
     "dgp_dist_product": (_i, [_vp, _i, _vp, _vp]),
     "dgp_dist_grad_partial": (_i, [_vp, _dp, _vp, _vp, _vp, _vp]),

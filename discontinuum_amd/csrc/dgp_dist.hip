@@ -521,6 +521,26 @@ int dgp_dist_alpha_partial(dgp_dist* p, const void* z, void* alpha_part, void* s
   return wrap((int)hipGetLastError(), "dgp_dist_alpha_partial");
 }
 
+// fp32 handles: the residual of the refinement step (dgp_api.hip::run_refine is the single-plan counterpart).  K^ is
+// re-evaluated in double from the inputs, which every rank holds: each rank computes the WHOLE vector -- no exchange, the
+// same bits everywhere, n^2 / 2 kernel evaluations against the n^3 / world of the step.  The tile sums (N / 64)^2 x 64
+// doubles = N^2 / 8 bytes live in the K^^-1 slab, which nothing has written yet at stage 2.
+int dgp_dist_residual(dgp_dist* p, const double* theta, const void* noise, const void* r, const void* alpha, double* rho64,
+                      void* rho32, void* stream) {
+  DIST_CHECK(p);
+  if (!theta || !noise || !r || !alpha || !rho64 || !rho32) return fail(DGP_E_ARG, "dgp_dist_residual: null argument");
+  if (p->dtype != DGP_F32) return fail(DGP_E_ARG, "dgp_dist_residual: fp32 handles only (fp64 needs no refinement)");
+  if (p->stage != 2)
+    return fail(DGP_E_STATE, "dgp_dist_residual: call between the factorisation and the inverse products (the K^^-1 slab is its scratch)");
+  const size_t nb = (size_t)(p->N / 64), need = nb * nb * 64 * sizeof(double);
+  if (need > p->elem * (size_t)p->N * (size_t)p->Cl)
+    return fail(DGP_E_WORKSPACE, "dgp_dist_residual: the K^^-1 slab is smaller than the tile sums (more than 32 ranks)");
+  const int rc = gram_residual<float>(p->model, p->d, (const float*)p->Xt, p->N, (int)p->n, theta, (const float*)noise, (const float*)r,
+                                      (const float*)alpha, (double*)p->S, rho64, (float*)rho32, (hipStream_t)stream, Batch(), 0, 0,
+                                      nullptr, nullptr);
+  return wrap(rc, "dgp_dist_residual");
+}
+
 int dgp_dist_pack_inverse(dgp_dist* p, int group, void* panel, void* stream) {
   DIST_CHECK(p);
   DIST_GROUP(p, group);

@@ -178,8 +178,9 @@ class DistributedFit:
 
     def __init__(self, model: str, n: int, d: int, dtype=torch.float64, device="cuda", rank: int | None = None,
                  world: int | None = None, group_panels: int | None = None, group=None, lookahead: bool = True, comm=None,
-                 force_collectives: bool | None = None):
-        """``comm``: the communicator (default ``TorchComm`` on ``group`` / the default process group; ``ThreadComm`` for
+                 force_collectives: bool | None = None, refine: bool = True):
+        """``refine`` (fp32 only, the single plan's ``DGP_OPT_REFINE``): one step of iterative refinement of alpha and the
+        quadratic form against an fp64 residual.  ``comm``: the communicator (default ``TorchComm`` on ``group`` / the default process group; ``ThreadComm`` for
         in-process ranks).  ``force_collectives`` (default: environment ``DGP_DIST_FORCE_COLLECTIVES``): issue every
         collective even with one rank."""
         mid = model_id(model)
@@ -197,6 +198,7 @@ class DistributedFit:
         self.world, self.rank = self.comm.world, self.comm.rank
         self.model, self.n, self.d, self.dtype, self.device = model, int(n), int(d), dtype, torch.device(device)
         self.lookahead = bool(lookahead)
+        self.refine = bool(refine) and dtype == torch.float32
         h = C.c_void_p()
         _lib.check(self.lib.dgp_dist_create(mid, _DTYPES[dtype], self.n, self.d, self.rank, self.world,
                                             int(group_panels), C.byref(h)), "dgp_dist_create")
@@ -421,6 +423,21 @@ class DistributedFit:
             self._sum(alpha)
             out = torch.zeros(_lib.OUT_LEN, dtype=dt, device=dev)
             quad = (z.double() * z.double()).sum()
+            if self.refine:
+                # rho = r - K^ alpha0 in double (K^ re-evaluated, every rank the whole vector); delta = K^^-1 rho from the
+                # fp32 factor; quad = r^T alpha0 + rho^T (alpha0 + delta) is second-order accurate in delta's error
+                rho64 = torch.empty(N, dtype=torch.float64, device=dev)
+                rho32 = torch.empty(N, dtype=dt, device=dev)
+                self._call("dgp_dist_residual", th, _ptr(noise), _ptr(r), _ptr(alpha), _ptr(rho64), _ptr(rho32))
+                self._call("dgp_dist_solve_partial", _ptr(rho32), _ptr(z))
+                self._sum(z)
+                delta = torch.empty(N, dtype=dt, device=dev)
+                self._call("dgp_dist_alpha_partial", _ptr(z), _ptr(delta))
+                self._sum(delta)
+                a0 = alpha.double()
+                a1 = a0 + delta.double()
+                quad = (r.double() * a0[:n]).sum() + (rho64 * a1).sum()
+                alpha = a1.to(dt)
             bad = stat64[1] != 0
             nll = 0.5 * quad + 0.5 * stat64[0] + 0.5 * n * math.log(2.0 * math.pi)
             out[_lib.OUT_NLL] = torch.where(bad, torch.full_like(nll, float("nan")), nll).to(dt)

@@ -242,6 +242,10 @@ int dgp_plan_get_timing(dgp_plan* plan, double* ms_out);
  *   dgp_dist_status -> (local log-determinant, local info)     sum / max over the ranks
  *   dgp_dist_solve_partial(r) -> z_part (N)                    sum over the ranks: z = L^-1 r ;  r^T K^^-1 r = z^T z
  *   dgp_dist_alpha_partial(z) -> alpha_part (N)                sum over the ranks: alpha = K^^-1 r
+ *   fp32 handles, one refinement step (the single plan's DGP_OPT_REFINE):
+ *     dgp_dist_residual(alpha) -> rho64, rho32 (N)             every rank, no exchange: rho = r - K^ alpha, K^ re-evaluated
+ *                                                              in double; then delta = K^^-1 rho32 by the two calls above,
+ *                                                              alpha += delta, r^T K^^-1 r = r^T alpha0 + rho^T (alpha0 + delta)
  *   for g = 0 .. groups-1:   dgp_dist_pack_inverse(g, panel)  owner: its columns of L^-1 from the diagonal down
  *                            <broadcast>
  *                            dgp_dist_product(g, panel)        every rank: K^^-1 [group g rows, its columns >= g]
@@ -266,6 +270,10 @@ int dgp_dist_invert(dgp_dist* h, int group, const void* panel_dev, void* stream)
 int dgp_dist_status(dgp_dist* h, void* stat_dev /* 2 elements */, void* stream);
 int dgp_dist_solve_partial(dgp_dist* h, const void* r_dev, void* z_part_dev, void* stream);
 int dgp_dist_alpha_partial(dgp_dist* h, const void* z_dev, void* alpha_part_dev, void* stream);
+/* fp32 only; between the factorisation and dgp_dist_pack_inverse (the K^^-1 slab is its scratch: N^2 / 8 bytes, i.e. at
+ * most 32 ranks).  rho64: N doubles; rho32: N floats (the same vector rounded, the right-hand side of the solves). */
+int dgp_dist_residual(dgp_dist* h, const double* theta_host, const void* noise_dev, const void* r_dev, const void* alpha_dev,
+                      double* rho64_dev, void* rho32_dev, void* stream);
 int dgp_dist_pack_inverse(dgp_dist* h, int group, void* panel_dev, void* stream);
 int dgp_dist_product(dgp_dist* h, int group, const void* panel_dev, void* stream);
 int dgp_dist_grad_partial(dgp_dist* h, const double* theta_host, const void* alpha_dev, void* dtheta_part_dev,

@@ -159,14 +159,14 @@ def test_not_positive_definite_is_reported(gpu_device):
 # device copies).  What this pins at world = 8: the block-cyclic ownership maps, ragged last groups, ranks with several
 # / one / no groups, the lookahead schedule and the partial-sum reductions.  It does NOT pin torch.distributed / RCCL
 # behaviour at eight ranks -- that stays unmeasured until a node exists.
-def _thread_world(world, model, d, n, W, dtype, dev, seed=7, lookahead=True):
+def _thread_world(world, model, d, n, W, dtype, dev, seed=7, lookahead=True, **kw):
     from discontinuum_amd.dist_chol import DistributedFit, run_thread_ranks
 
     X, r, noise, theta = make_case(model, d, n, seed=seed, perturb=0.2)
     Xd, rd, nd = (t.to(dev, dtype).contiguous() for t in (X, r, noise))
 
     def rank_body(comm):
-        ctx = DistributedFit(model, n, d, dtype=dtype, device=dev, group_panels=W, lookahead=lookahead, comm=comm)
+        ctx = DistributedFit(model, n, d, dtype=dtype, device=dev, group_panels=W, lookahead=lookahead, comm=comm, **kw)
         ctx.set_inputs(Xd)
         out = ctx.fit_step(theta, rd, nd)
         return out.cpu().double(), ctx.alpha.cpu().double(), ctx.dnoise.cpu().double(), ctx.hbm_bytes(), dict(comm.calls), ctx.ngroups
@@ -226,10 +226,43 @@ def test_world8_thread_ranks_fp32_n16384_match_the_single_plan(gpu_device):
     e_grad = ((g - gr).abs().max() / gr.abs().max()).item()
     e_alpha = (torch.linalg.norm(alpha - ref_a) / torch.linalg.norm(ref_a)).item()
     _record(test="world8_threads_n16384_fp32_vs_single_plan", nll_rel=e_nll, grad_rel=e_grad, alpha_rel=e_alpha)
-    assert e_nll <= 1e-4, e_nll  # measured 2.9e-5
-    assert e_grad <= 3e-4, e_grad  # measured 6.7e-5
-    assert e_alpha <= 6e-3, e_alpha  # measured 1.3e-3
+    # both sides refine alpha and the quadratic form against an fp64 residual since round 4 (before: 2.9e-5 / 6.7e-5 / 1.3e-3)
+    assert e_nll <= 2e-6, e_nll  # measured 7.5e-8
+    assert e_grad <= 2e-4, e_grad  # measured 2.0e-5
+    assert e_alpha <= 1e-5, e_alpha  # measured 2.8e-7
     assert all(torch.equal(o[0], out) for o in res)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_fp32_refinement_across_ranks(world, gpu_device):
+    """fp32 handles refine alpha and the quadratic form once against an fp64 residual (dgp_dist_residual; the single plan's
+    DGP_OPT_REFINE): against the fp64 ORACLE, rating-gp n = 3000 (the ill-conditioned kernel of BASELINE config 3).
+    Bounds = SURVEY section 8d's fp32 row (NLL rel 1e-4 n / 1024, gradients rel 1e-2) with the measured values beside them."""
+    from discontinuum_amd import _lib
+    from tests.test_gpu_fullsize import _record
+
+    model, d, n, W = "rating", 2, 3000, 2
+    errs = {}
+    for refine in (False, True):
+        res, (X, r, noise, theta) = _thread_world(world, model, d, n, W, torch.float32, gpu_device, seed=5, refine=refine)
+        val, g_theta, g_r, g_noise = orc.nll_data_and_grads(model, X, r, noise, theta)
+        out, alpha, dnoise, _, calls, _ = res[0]
+        P = theta.numel()
+        assert out[_lib.OUT_INFO] == 0
+        assert all(torch.equal(o[0], out) and torch.equal(o[1], alpha) for o in res)  # the same bits on every rank
+        if world > 1:
+            assert calls["all_reduce"] == (5 if refine else 3)  # + the refinement's two solves
+        g = out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + P]
+        errs[refine] = dict(nll=(abs(out[_lib.OUT_NLL] - val.item()) / abs(val.item())).item(),
+                            alpha=(torch.linalg.norm(alpha - g_r) / torch.linalg.norm(g_r)).item(),
+                            grad=((g - g_theta).abs().max() / g_theta.abs().max()).item(),
+                            dnoise=((dnoise - g_noise).abs().max() / g_noise.abs().max()).item())
+    _record(test=f"dist_fp32_refinement_world{world}", refined=errs[True], unrefined=errs[False])
+    e = errs[True]
+    assert e["nll"] <= 1e-4 * n / 1024, errs
+    assert e["alpha"] <= 1e-4 and e["alpha"] <= 0.2 * errs[False]["alpha"], errs
+    assert e["grad"] <= 1e-2 and e["dnoise"] <= 1e-2, errs
+    assert e["nll"] <= errs[False]["nll"] + 1e-7, errs
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -273,7 +306,8 @@ def test_rccl_is_really_called_with_one_rank(gpu_device):
     val, g_theta, g_r, _ = orc.nll_data_and_grads("loadest", X, r, noise, theta)
     for key, tol_nll, tol_g in ((str(torch.float64), 1e-10, 1e-8), (str(torch.float32), 1e-4, 1e-2)):
         out, alpha, calls, ng = rows[key]
-        assert calls == {"broadcast": 2 * ng, "all_reduce": 3, "all_gather": 1}, calls
+        # (fp32 handles refine alpha once: two more solves, i.e. two more sums)
+        assert calls == {"broadcast": 2 * ng, "all_reduce": 5 if key == str(torch.float32) else 3, "all_gather": 1}, calls
         assert out[_lib.OUT_INFO] == 0
         assert abs(out[_lib.OUT_NLL] - val.item()) <= tol_nll * abs(val.item())
         g = torch.tensor(out[_lib.OUT_DTHETA:_lib.OUT_DTHETA + 11])
