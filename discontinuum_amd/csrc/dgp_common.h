@@ -11,7 +11,7 @@
 #include <stdint.h>
 
 #define DGP_TILE 128  // block size of every blocked algorithm == padding quantum of N
-#define DGP_MAX_BATCH 8  // sites one plan can carry in lockstep (blockIdx.z of every fit-step kernel)
+#define DGP_MAX_BATCH 8  // sites whose hyperparameters travel BY VALUE in the kernel arguments (larger batches, up to 1024, read a device array)
 
 typedef double dgp_d4 __attribute__((ext_vector_type(4)));
 typedef float dgp_f4 __attribute__((ext_vector_type(4)));

@@ -9,7 +9,7 @@ namespace dgp {
 
 inline long round_up(long n, long q) { return (n + q - 1) / q * q; }
 
-// A batched plan carries B <= DGP_MAX_BATCH sites in lockstep: every fit-step kernel is launched once with
+// A batched plan carries B <= DGP_MAX_BATCH_SITES sites in lockstep: every fit-step kernel is launched once with
 // gridDim.z = B and finds its site's buffers at blockIdx.z * stride (workspace buffers: `ws` elements of the plan's
 // dtype; caller arrays: n or DGP_OUT_LEN).  B = 1 is the plain single-site plan.
 #define DGP_MAX_BATCH_HOST 8     // == DGP_MAX_BATCH in dgp_common.h: hyperparameters by value up to here
