@@ -235,11 +235,11 @@ def test_config5_single_matrix_on_one_gpu(gpu_device):
     """BASELINE config 5's matrix (n = 65536, d = 3, fp32) at FULL size through BOTH code paths on one GPU:
 
     * the single-GPU plan (48 GiB of workspace): the system is solved to fp32 accuracy (||K^ alpha - r|| / ||r|| measured
-      3.8e-3; tolerance 1.2e-2);
+      8.7e-4 with the refinement step, against the fp32 copy of K^; tolerance 3e-3);
     * the DISTRIBUTED path (`DistributedFit`, column slabs, 64 groups of eight panels, one rank -- the code the 8-GPU run
       executes, with every collective skipped): same residual bound for ITS alpha, and NLL / quadratic form / log-det /
       every theta-gradient against the single-GPU plan on the same matrix.  Both are fp32 with different summation
-      orders on a matrix with cond ~ 1e7, so the bounds are what fp32 can give there: 4x the measured differences
+      orders on a matrix with cond ~ 1e7; the bounds are 3 - 10x the measured differences
       (gpurun_out/fullsize_parity.jsonl)."""
     from discontinuum_amd import _lib
     from discontinuum_amd.backend import GPPlan
@@ -292,9 +292,11 @@ def test_config5_single_matrix_on_one_gpu(gpu_device):
     _record(test="config5_loadest_n65536_fp32", residual_rel=e_res, dist_residual_rel=e_res_d, dist_vs_plan_nll_rel=e_nll,
             dist_vs_plan_quad_rel=e_quad, dist_vs_plan_logdet_rel=e_logdet, dist_vs_plan_grad_rel=e_grad,
             dist_vs_plan_alpha_rel=e_alpha, dist_vs_plan_dnoise_rel=e_dnoise, nll=out[0].item(), dist_nll=dout[0].item())
-    assert e_res < 1.2e-2, e_res
-    assert e_res_d < 1.2e-2, e_res_d
-    # measured (round 3): NLL 1.2e-4, quad 9.7e-5, log-det 8.7e-7, gradient 1.8e-4, alpha 7.8e-3, dnoise 1.2e-2
-    assert e_nll < 5e-4 and e_logdet < 4e-6 and e_quad < 4e-4, (e_nll, e_quad, e_logdet)
-    assert e_grad < 8e-4, e_grad
-    assert e_alpha < 3e-2 and e_dnoise < 5e-2, (e_alpha, e_dnoise)
+    # round 4: BOTH paths refine alpha and the quadratic form once against an fp64 residual, and K^^-1 sums its products
+    # small-to-large.  Measured: residuals 8.7e-4 / 8.7e-4 (round 3: 3.8e-3), NLL / quad / log-det equal in every fp32
+    # digit, gradient 5.8e-5, alpha 5.0e-6, dnoise 6.5e-6 (round 3: 1.2e-4, 9.7e-5, 8.7e-7, 1.8e-4, 7.8e-3, 1.2e-2)
+    assert e_res < 3e-3, e_res
+    assert e_res_d < 3e-3, e_res_d
+    assert e_nll < 2e-6 and e_logdet < 2e-6 and e_quad < 2e-6, (e_nll, e_quad, e_logdet)
+    assert e_grad < 3e-4, e_grad
+    assert e_alpha < 5e-5 and e_dnoise < 5e-5, (e_alpha, e_dnoise)
