@@ -309,6 +309,9 @@ int dgp_plan_set_option(dgp_plan* p, int key, int64_t value) {
       if (value < 0 || value > 64) return fail(DGP_E_ARG, "dgp_plan_set_option: value out of range");
       (key == DGP_OPT_SYRK_ORDER ? p->tune.syrk_super : p->tune.lauum_super) = (int)value;
       return 0;
+    case DGP_OPT_CHAIN_YIELD:
+      p->tune.chain_yield = value ? 1 : 0;
+      return 0;
     case DGP_OPT_REFINE:
       if (p->dtype != DGP_F32 && value) return fail(DGP_E_ARG, "dgp_plan_set_option: refinement applies to float32 plans");
       p->refine = value ? 1 : 0;
@@ -326,6 +329,7 @@ int dgp_plan_get_option(const dgp_plan* p, int key, int64_t* value) {
     case DGP_OPT_REFINE: *value = p->refine; return 0;
     case DGP_OPT_SYRK_ORDER: *value = p->tune.syrk_super; return 0;
     case DGP_OPT_LAUUM_ORDER: *value = p->tune.lauum_super; return 0;
+    case DGP_OPT_CHAIN_YIELD: *value = p->tune.chain_yield; return 0;
     default: return fail(DGP_E_ARG, "dgp_plan_get_option: unknown option");
   }
 }

@@ -107,31 +107,50 @@ __global__ __launch_bounds__(256, 2) void trsm_kernel(T* __restrict__ A, const T
 // ceil(t / slots) rounds and its last round is on average half empty.  The first `nfull` tiles (whole rounds) are
 // done as 128 x 128 tiles; the rest is cut into `split` pieces each (2: 64 x 128 halves, 4: 64 x 64 quarters),
 // which fills the last round at a fraction of its time (SyrkShape picks the cheapest cut).
-template <typename T, int BM, int BN>
+// POLITE (single-site plans): the waves of a 128 x 128 tile give their CU to the diagonal-block kernel while it runs there
+// (dgp_common.h: yield_if_asked); `me` = cu_code() of this wave
+struct YieldHook {
+  const unsigned* word;
+  unsigned me;
+  const unsigned* copy;  // this wave's 64 words of LDS
+  __device__ __forceinline__ void operator()(int) const {
+    const unsigned seen = __builtin_amdgcn_readfirstlane(copy[0]);  // (the first round reads whatever LDS held: a false match costs one scalar load)
+    yield_if_asked(word, me, seen);
+    yield_refresh(word, (unsigned)(size_t)(dgp_lds_ptr)copy);
+  }
+};
+template <typename T, int BM, int BN, bool POLITE = false>
 __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int nk, long row0, long col0,
-                                          T* __restrict__ smem) {
+                                          T* __restrict__ smem, const unsigned* yield_word = nullptr, unsigned me = 0,
+                                          const unsigned* yield_copy = nullptr) {
   using K = TileCore<T, true, true, BM, BN, (BM == 128 && BN == 128) ? Prefetch<T>::SYRK : 1>;
   using G = typename K::G;
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
   typename G::acc_t keep[G::MI][G::NI];
   trailing_begin<T, G, K::DMA>(acc, keep, C, ld);
-  K::run(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc);
+  if constexpr (POLITE)
+    K::run_hooked(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc, YieldHook{yield_word, me, yield_copy});
+  else
+    K::run(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc);
   trailing_end<T, G, K::DMA>(acc, keep, C, ld);
 }
 
-template <typename T>
+template <typename T, bool POLITE = false>
 __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg, int nfull,
-                                                                                   int split, long bs, int nt = 0, int super = 0) {
+                                                                                   int split, long bs, int nt = 0, int super = 0,
+                                                                                   const unsigned* yield_word = nullptr) {
   A = site(A, bs);
   __shared__ T smem[TileCore<T, true, true>::SMEM_ELEMS];
+  __shared__ unsigned yield_copy[POLITE ? 4 * 64 : 1];  // per wave: its copy of the yield word (YieldHook)
   const int b = (int)blockIdx.x;
   int bi, bj;
   if (b < nfull) {
     // all tiles cost the same: remap freely -- consecutive logical tiles on one XCD; `super` picks the logical order
     if (super > 0) super_decode(xcd_remap(b, nfull), nt, super, bi, bj);
     else tri_decode(xcd_remap(b, nfull), bi, bj);
-    syrk_tile<T, 128, 128>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem);
+    syrk_tile<T, 128, 128, POLITE>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem, yield_word, POLITE ? cu_code() : 0u,
+                                   yield_copy + (POLITE ? 64 * __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0));
     return;
   }
   const int sub = b - nfull;
@@ -157,6 +176,7 @@ const Tuning& default_tuning() {
     v.trtri_small = getenv("DGP_TRTRI_SMALL") ? atol(getenv("DGP_TRTRI_SMALL")) : 1024;
     v.syrk_super = getenv("DGP_SYRK_ORDER") ? atoi(getenv("DGP_SYRK_ORDER")) : 0;
     v.lauum_super = getenv("DGP_LAUUM_ORDER") ? atoi(getenv("DGP_LAUUM_ORDER")) : 0;
+    v.chain_yield = getenv("DGP_CHAIN_YIELD") ? atoi(getenv("DGP_CHAIN_YIELD")) : 1;
     if (v.syrk_slots < 1) v.syrk_slots = 1;
     return v;
   }();
@@ -246,6 +266,26 @@ static bool f32_diag64() {
   }();
   return v;
 }
+// single-site plans: the bulk update's waves yield their CU to the diagonal-block kernel (dgp_common.h: yield_if_asked)
+static bool yields(const Batch& bt) { return bt.B == 1 && bt.tuning().chain_yield != 0; }
+// one bulk launch of the trailing update (SyrkShape), polite or not
+template <typename T>
+static void launch_bulk(T* A, long N, int k, int nk, int jbeg, const SyrkShape& sh, int nt, int* info, hipStream_t s, const Batch& bt) {
+  const int nbk = (int)(N / NB);
+  const dim3 grid(sh.grid, 1, (unsigned)bt.B);
+  // One site, chain-bound sizes: 14 KB of unused dynamic LDS per workgroup hold the bulk update at TWO workgroups per CU, so
+  // that trsm / the column updates of the chain find a slot on every CU at once instead of waiting for tiles to retire (first
+  // panel of a pair at n = 8192: trsm 59 -> 33 us, column update 77 -> 30).  Measured (step, ms): n = 6144 6.72 -> 6.69,
+  // 8192 11.93 -> 11.89, 12288 33.3 -> 32.7, 16384 fp64 71.6 -> 70.9, 16384 fp32 38.95 -> 38.55; n >= 24576 (bound by the
+  // bulk launches) and n <= 4096 (one round of tiles anyway): nothing or slightly worse -- hence the window.
+  static const int pad_env = getenv("DGP_BULK_LDS_PAD") ? atoi(getenv("DGP_BULK_LDS_PAD")) : 14336;
+  const size_t pad = (bt.B == 1 && nbk >= 40 && nbk <= 160) ? (size_t)pad_env : 0;
+  if (yields(bt))
+    syrk_kernel<T, true><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super,
+                                              reinterpret_cast<const unsigned*>(info + CHAIN_YIELD));
+  else
+    syrk_kernel<T, false><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
+}
 template <typename TS, typename TC>
 static void launch_diag_as(TS* A, long N, long k0, TS* Tinv, TS* logdet, int* info, hipStream_t s, Batch bt, bool init,
                            double* logdet_hi, int done_index, int done_value) {
@@ -258,7 +298,7 @@ static void launch_diag_as(TS* A, long N, long k0, TS* Tinv, TS* logdet, int* in
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   potrf_diag_fast_kernel<TS, TC><<<dim3(1, 1, (unsigned)bt.B), 256, bytes, s>>>(
       A, N, k0, Tinv, logdet, info, bt.ws, bt.ws * (long)sizeof(TS) / (long)sizeof(int), init ? 1 : 0, POTRF_INFO_INTS, logdet_hi,
-      done_index, done_value);
+      done_index, done_value, yields(bt) ? CHAIN_YIELD : -1);
 }
 // the fp32 plans' unrounded log-determinant lives in the scalar block right behind (log-det, quad): element 2..3 as ONE double
 template <typename T>
@@ -302,7 +342,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s);
         {
           const SyrkShape sh((int)tri(nbk - k - 1), bt.tuning().syrk_slots / bt.B);
-          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s>>>(A, N, k, 1, k + 1, sh.nfull, sh.split, bt.ws, nbk - k - 1, bt.tuning().syrk_super);
+          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s>>>(A, N, k, 1, k + 1, sh.nfull, sh.split, bt.ws, nbk - k - 1, bt.tuning().syrk_super);  // (same stream as the chain: nothing to yield to)
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s);
         flop += tile_flop * tri(nbk - k - 1) * bt.B;
@@ -349,7 +389,7 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
         {
           const SyrkShape sh((int)tri(nbk - k0 - G), bt.tuning().syrk_slots / bt.B);
-          syrk_kernel<T><<<dim3(sh.grid, 1, Bz), 256, 0, s2>>>(A, N, k0 - G, G, k0 + G, sh.nfull, sh.split, bt.ws, nbk - k0 - G, bt.tuning().syrk_super);
+          launch_bulk<T>(A, N, k0 - G, G, k0 + G, sh, nbk - k0 - G, info, s2, bt);
         }
         if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
         flop += (double)G * tile_flop * tri(nbk - k0 - G) * bt.B;
@@ -636,7 +676,7 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
     hipStreamWaitEvent(s2, ER[k], 0);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns], s2);
     const SyrkShape sh((int)tri(nbk - k - 3), bt.tuning().syrk_slots);
-    syrk_kernel<T><<<dim3(sh.grid, 1, 1), 256, 0, s2>>>(A, N, kfirst, nk, k + 3, sh.nfull, sh.split, 0, nbk - k - 3, bt.tuning().syrk_super);
+    launch_bulk<T>(A, N, kfirst, nk, k + 3, sh, nbk - k - 3, info, s2, bt);
     if (syrk_ev) hipEventRecord(syrk_ev[2 * ns + 1], s2);
     flop += (double)nk * tile_flop * tri(nbk - k - 3);
     ++ns;
@@ -1424,3 +1464,10 @@ DGP_INST(double)
 DGP_INST(float)
 
 }  // namespace dgp
+
+#ifdef DGP_DIAG_LOG
+// measurement builds only (scripts/diag_in_situ.py): the diagonal-block kernel's in-situ log, 4 x 1024 words
+extern "C" int dgp_debug_diag_log(unsigned long long* out_host) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(dgp::dgp_diag_log), sizeof(unsigned long long) * 4 * 1024);
+}
+#endif

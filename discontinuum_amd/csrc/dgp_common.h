@@ -113,4 +113,49 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// ---- cooperative yield to the panel chain (single-site plans) ------------------------------------------------------------
+// The diagonal-block kernel of the factorisation is ONE workgroup of dependent fp64 latency chains on the critical path.  Sharing
+// its CU with two or three workgroups of a bulk update makes it 4-8 times slower (in-kernel stamps: 24 -> 120-206 us at
+// n = 16384 fp32, 38 -> 90-100 us at n = 8192 fp64; the wait for a slot is 2-15 us of that: scripts/diag_in_situ.py) -- the
+// MFMA pipe, the LDS and the issue ports are occupied by waves that do not care about 30 us.  So the block kernel publishes
+// the CU it runs on (cu_code) in a word for its lifetime, and every wave of a bulk tile looks at the word every few chunks of
+// its k-loop: on that CU it sleeps until the word changes (bounded: 96 x ~2 us).  Two or three workgroups of ~768 pause for
+// ~30 us; the chain step that every bulk launch behind it waits for gets the CU to itself.  A hint only: results do not depend
+// on it, a stale or foreign word costs at most the bound.
+__device__ __forceinline__ unsigned cu_code() {  // (XCC, SE, SH, CU) of this wave + 1: never 0
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+  const unsigned cu = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4) & 255u;    // HW_REG_HW_ID[15:8]: CU_ID, SH_ID, SE_ID
+  return ((xcc << 8) | cu) + 1u;
+}
+// Per round of the k-loop a wave (i) looks at ITS copy of the word in LDS and (ii) refreshes the copy with one more
+// direct-to-LDS load (global_load_lds_dword, all lanes the same address -> 256 bytes of LDS per wave): the load joins the
+// operand loads' in-order vmcnt queue, so the copy is complete a round later without any wait of its own -- a blocking scalar
+// load per check measured 2.3x on the bulk update (the memory system is saturated: several us per load).  Only a wave whose
+// copy matches enters the sleep loop, which re-reads the real word (scalar, glc: past the scalar cache) until it changes.
+// All control flow is inside the assembly block: the caller's register allocation never sees a branch (dgp_gemm_dma.h: joins
+// around 128 live accumulators spill).
+__device__ __forceinline__ void yield_refresh(const unsigned* word, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 sc1" ::"v"(0u), "s"(word), "s"(lds_byte_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void yield_if_asked(const unsigned* word, unsigned me, unsigned seen) {
+  unsigned t, cnt;
+  asm volatile(
+      "s_cmp_lg_u32 %5, %3\n\t"
+      "s_cbranch_scc1 Lyield_done%=\n\t"
+      "s_movk_i32 %1, 96\n"
+      "Lyield_loop%=:\n\t"
+      "s_load_dword %0, %2, 0x0 glc\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_cmp_lg_u32 %0, %3\n\t"
+      "s_cbranch_scc1 Lyield_done%=\n\t"
+      "s_sleep 32\n\t"
+      "s_sub_u32 %1, %1, 1\n\t"
+      "s_cmp_lg_u32 %1, 0\n\t"
+      "s_cbranch_scc1 Lyield_loop%=\n"
+      "Lyield_done%=:"
+      : "=&s"(t), "=&s"(cnt)
+      : "s"(word), "s"(me), "s"(0), "s"(seen)
+      : "memory", "scc");
+}
+
 }  // namespace dgp

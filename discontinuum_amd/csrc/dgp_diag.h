@@ -148,6 +148,23 @@ __device__ long long dgp_diag_prof[16];
 #else
 #define DGP_DIAG_STAMP(i)
 #endif
+// optional in-situ log (scripts/diag_in_situ.py builds a second library with -DDGP_DIAG_LOG): per 128-column block the
+// 100 MHz wall clock at the workgroup's first and last instruction and where it ran -- the profiler's kernel duration
+// minus (end - begin) is the time the launch spent waiting to be placed
+#ifdef DGP_DIAG_LOG
+__device__ unsigned long long dgp_diag_log[4 * 1024];
+#define DGP_DIAG_LOG_BEGIN(k)                                                                                       \
+  if (threadIdx.x == 0 && blockIdx.z == 0 && (k) < 1024) {                                                           \
+    dgp_diag_log[4 * (k)] = wall_clock64();                                                                          \
+    dgp_diag_log[4 * (k) + 1] = ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15) << 16) | \
+                                (unsigned long long)(__builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4) & 255);      \
+  }
+#define DGP_DIAG_LOG_END(k) \
+  if (threadIdx.x == 0 && blockIdx.z == 0 && (k) < 1024) dgp_diag_log[4 * (k) + 2] = wall_clock64();
+#else
+#define DGP_DIAG_LOG_BEGIN(k)
+#define DGP_DIAG_LOG_END(k)
+#endif
 
 // TS = the matrix's storage type, T = the type the block is factored and inverted in.  T = TS for fp64 plans; fp32
 // plans use T = double (MIXED-PRECISION PANEL): the block is promoted when it is loaded into LDS, factored and inverted
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(TS* __restrict__ A
                                                               TS* __restrict__ Tinv, TS* __restrict__ logdet,
                                                               int* __restrict__ info, long bs, long ibs, int init,
                                                               int ninit, double* __restrict__ logdet_hi, int done_index,
-                                                              int done_value) {
+                                                              int done_value, int yield_index = -1) {
   A = site(A, bs);
   Tinv = site(Tinv, bs);
   logdet = site(logdet, bs);
@@ -185,6 +202,7 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(TS* __restrict__ A
   // this workgroup usually shares its CU with waves of the bulk trailing update: win the issue arbitration
   __builtin_amdgcn_s_setprio(3);
   DGP_DIAG_STAMP(0)
+  DGP_DIAG_LOG_BEGIN((int)(k0 / 128))
 
   // ---- load the lower block triangle (diagonal sub-blocks complete: they are symmetric)
   // (fully unrolled: all 36 global loads are in flight before the first LDS store)
@@ -198,6 +216,10 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(TS* __restrict__ A
     for (int b = 0; b < DGP_DTRI; ++b) sL[b * DGP_DBLK + ti * DGP_DS + tj] = tmp[b];
   }
   __syncthreads();
+  // from here to the end this workgroup is a chain of dependent latencies: ask the bulk update's waves on THIS CU to sleep
+  // meanwhile (dgp_common.h: yield_if_asked; after the barrier, so that the init block's reset of the word is behind us)
+  if (yield_index >= 0 && t == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(&info[yield_index]), cu_code(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // ---- blocked right-looking Cholesky on the sub-blocks, software-pipelined: while wave 0 runs the
   // sequential 16-pivot sweep of the NEXT diagonal sub-block (which only needs that one sub-block
@@ -320,6 +342,9 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(TS* __restrict__ A
     if (bad < 128) atomicCAS(info, 0, (int)(k0 + bad + 1));
   }
   DGP_DIAG_STAMP(7)
+  DGP_DIAG_LOG_END((int)(k0 / 128))
+  if (yield_index >= 0 && t == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(&info[yield_index]), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // split panel chain: publish "this block is factored" for the rest stream's trsm, which was launched before this
   // kernel finished and polls the word (no event record / stream wait on the critical stream).  Every thread's stores of
   // L and L^-1 precede the barrier; the release makes them visible to the agent.

@@ -131,12 +131,15 @@ struct DmaGemm {
   struct NoEpilogue {
     __device__ __forceinline__ void operator()() const {}
   };
+  struct NoHook {  // hook(round): once per round of SLOTS chunks of the plain steady loop (dgp_common.h: yield_if_asked)
+    __device__ __forceinline__ void operator()(int) const {}
+  };
   // epi: with TRI the caller's epilogue (its stores of acc) runs INSIDE each of the unrolled tail variants -- merging the
   // 128 accumulator registers of several control-flow paths after the loop is what the register allocator cannot do without
   // second copies (thousands of spills); with its own copy of the epilogue no path ever joins another.
-  template <bool REV = false, int TRI = TRI_NONE, typename Epi = NoEpilogue>
+  template <bool REV = false, int TRI = TRI_NONE, typename Epi = NoEpilogue, typename Hook = NoHook>
   static __device__ __forceinline__ void run(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int ktiles,
-                                             T* __restrict__ smem, acc_t (&acc)[4][4], Epi epi = Epi()) {
+                                             T* __restrict__ smem, acc_t (&acc)[4][4], Epi epi = Epi(), Hook hook = Hook()) {
     static_assert(TRI == TRI_NONE || IL, "zero-work skipping needs the interleaved group map");
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -246,8 +249,9 @@ struct DmaGemm {
         else chunk(slot);
       };
       frags(0, 0);
-      int c0 = 0;
-      for (; c0 + 2 * SLOTS <= C; c0 += SLOTS) {  // steady state, branch-free: every chunk of the round has a chunk SLOTS ahead
+      int c0 = 0, round = 0;
+      for (; c0 + 2 * SLOTS <= C; c0 += SLOTS, ++round) {  // steady state, branch-free: every chunk of the round has a chunk SLOTS ahead
+        hook(round);
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
           chunk_u(u);
@@ -335,6 +339,13 @@ struct TileCore {
                                              T* __restrict__ smem, typename G::acc_t (&acc)[G::MI][G::NI]) {
     if constexpr (DMA) D::template run<REV>(A, lda, B, ldb, ktiles, smem, acc);
     else G::template run<PF, REV>(A, lda, B, ldb, ktiles, smem, acc);
+  }
+  // the same with a per-round hook in the direct-to-LDS core's steady loop (the register-staged core ignores it)
+  template <typename Hook>
+  static __device__ __forceinline__ void run_hooked(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int ktiles,
+                                                    T* __restrict__ smem, typename G::acc_t (&acc)[G::MI][G::NI], Hook hook) {
+    if constexpr (DMA) D::template run<false, TRI_NONE, typename D::NoEpilogue, Hook>(A, lda, B, ldb, ktiles, smem, acc, typename D::NoEpilogue(), hook);
+    else G::template run<PF, false>(A, lda, B, ldb, ktiles, smem, acc);
   }
   // the k-range ends in a triangular diagonal block (TriMode); the register-staged core computes everything (same results).
   // `epi` = the caller's epilogue (its use of acc): it is the LAST thing this call does (see DmaGemm::run).

@@ -24,6 +24,7 @@ struct Tuning {
   long trtri_small;       // an inverse level with fewer 128-tiles (x batch) than this runs in 64 x 64 tiles (1024)
   int syrk_super;         // tile order of the bulk update: 0 = rows of the trailing matrix, S > 0 = S x S supertiles (experiment)
   int lauum_super;        // tile order of K^^-1 = L^-T L^-1: 0 = rows, S > 0 = S x S supertiles dealt round-robin over the XCDs
+  int chain_yield;        // single-site plans: bulk-update waves leave their CU to the diagonal-block kernel while it runs there (1)
 };
 const Tuning& default_tuning();
 struct Batch {
@@ -110,7 +111,8 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready_blocks, TrtriProgre
 #define CHAIN_FLAG0 2  /* info[2], info[3]: the split chain's progress counters (rest steps / bulk launches finished) */
 #define EARLY_CTR0 4
 #define EARLY_CTR_PAIRS 125
-#define POTRF_INFO_INTS (EARLY_CTR0 + 2 * EARLY_CTR_PAIRS + 2)
+#define POTRF_INFO_INTS (EARLY_CTR0 + 2 * EARLY_CTR_PAIRS + 3)
+#define CHAIN_YIELD (POTRF_INFO_INTS - 3)      /* cu_code() of the running diagonal-block kernel, else 0 (dgp_common.h: yield_if_asked) */
 #define CHAIN_DIAG_DONE (POTRF_INFO_INTS - 2)  /* diagonal blocks finished (split chain: the rest stream's trsm waits on it) */
 #define CHAIN_TICKET (POTRF_INFO_INTS - 1)     /* workgroup ticket of the rest stream's column-update kernel */
 // per-device table of compute units kept free of early-inverse workgroups (null if unavailable)

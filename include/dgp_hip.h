@@ -144,6 +144,11 @@ int dgp_plan_set_lookahead(dgp_plan* plan, int level);
  * bitwise those of the default order. */
 #define DGP_OPT_SYRK_ORDER 4
 #define DGP_OPT_LAUUM_ORDER 5
+/* single-site plans (default 1): while the diagonal-block kernel of the panel chain runs, the waves of the concurrent bulk
+ * update that share ITS compute unit sleep (a word in the plan's status block names the CU; bounded at ~0.2 ms) -- the
+ * block kernel is one workgroup of dependent latencies on the critical path and runs 3-5 times slower beside them.  A
+ * scheduling hint: results are bitwise the same with 0. */
+#define DGP_OPT_CHAIN_YIELD 6
 int dgp_plan_set_option(dgp_plan* plan, int key, int64_t value);
 int dgp_plan_get_option(const dgp_plan* plan, int key, int64_t* value_out);
 int dgp_plan_buffer(const dgp_plan* plan, int which, void** dev_ptr, int64_t* ld);

@@ -134,3 +134,33 @@ def test_ragged_batch_on_the_128_tile_kernels(model, d, sizes, dtype, gpu_device
         else:
             assert e_nll < 1e-4 * max(1.0, nb / 1024) and e_g < 1e-2 and e_a < 1e-2 and e_n < 2e-2, (b, e_nll, e_g, e_a, e_n)
         assert bool((dr[b, nb:] == 0).all()) and bool((dnoise[b, nb:] == 0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_chain_yield_is_a_scheduling_hint_only(dtype, gpu_device):
+    """`DGP_OPT_CHAIN_YIELD` (single-site plans: the bulk update's waves that share the diagonal-block kernel's compute unit
+    sleep while it runs; csrc/dgp_common.h `yield_if_asked`) changes WHEN tiles are computed, never what: the whole result
+    row, alpha and dnoise are bitwise the same with the hint off -- on the 128-tile bulk kernel that carries it (forced by
+    the tile selectors) and with the default selectors."""
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev, model, d, n = gpu_device, "loadest", 3, 2600
+    X, r, noise, theta = make_case(model, d, n, seed=4, perturb=0.3)
+    rd, nd = r.to(dev, dtype).contiguous(), noise.to(dev, dtype).contiguous()
+    for forced in (True, False):
+        rows = []
+        for hint in (1, 0, 1):
+            p = GPPlan(model, n, d, dtype=dtype, device=dev)
+            if forced:
+                force_big_tiles(p)
+            p.set_option(_lib.OPT_CHAIN_YIELD, hint)
+            assert p.get_option(_lib.OPT_CHAIN_YIELD) == hint
+            p.set_inputs(X.to(dev, dtype).contiguous())
+            out, alpha, dnoise = p.fit_step(theta, rd, nd)
+            out2 = p.fit_step(theta, rd, nd)[0]  # (and repeatable)
+            assert torch.equal(out, out2)
+            rows.append((out.cpu(), alpha.cpu(), dnoise.cpu()))
+        assert rows[0][0][_lib.OUT_INFO] == 0 and bool(torch.isfinite(rows[0][0][:15]).all())
+        for o, a, dn in rows[1:]:
+            assert torch.equal(o, rows[0][0]) and torch.equal(a, rows[0][1]) and torch.equal(dn, rows[0][2])
