@@ -279,6 +279,7 @@ static void launch_bulk(T* A, long N, int k, int nk, int jbeg, const SyrkShape& 
   // 8192 11.93 -> 11.89, 12288 33.3 -> 32.7, 16384 fp64 71.6 -> 70.9, 16384 fp32 38.95 -> 38.55; n >= 24576 (bound by the
   // bulk launches) and n <= 4096 (one round of tiles anyway): nothing or slightly worse -- hence the window.
   static const int pad_env = getenv("DGP_BULK_LDS_PAD") ? atoi(getenv("DGP_BULK_LDS_PAD")) : 14336;
+  // (batched plans: 64 x 4096 797 -> 789 fits/s, 32 x 8192 115.6 -> 115.0, 128 x 2048 no change -- their chain kernels are wide enough)
   const size_t pad = (bt.B == 1 && nbk >= 40 && nbk <= 160) ? (size_t)pad_env : 0;
   if (yields(bt))
     syrk_kernel<T, true><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super,
