@@ -195,9 +195,17 @@ def test_fit_sites_two_plans_match_sequential(gpu_device):
                     [noise] * 5, theta)
     bat = fit_sites(GPPlan("loadest", n, d, device=dev, lookahead=1, batch=4), [x for x, _ in data], [y for _, y in data],
                     [noise] * 5, theta)  # 5 sites through a batch of 4: one full chunk and one padded chunk
+    # several BATCHED plans, a contiguous share of the sites each on its own stream (3 + 2 sites over two plans of 3; and a
+    # third plan that gets no site at all)
+    bat2 = fit_sites([GPPlan("loadest", n, d, device=dev, lookahead=1, batch=3) for _ in range(2)], [x for x, _ in data],
+                     [y for _, y in data], [noise] * 5, theta)
+    bat3 = fit_sites([GPPlan("loadest", n, d, device=dev, lookahead=1, batch=3) for _ in range(3)], [x for x, _ in data][:4],
+                     [y for _, y in data][:4], [noise] * 4, theta)
     torch.cuda.synchronize()
     assert torch.equal(one, two)
     assert bat.shape == one.shape and (bat - one).abs().max() <= 1e-10 * one.abs().max()
+    assert bat2.shape == one.shape and (bat2 - one).abs().max() <= 1e-10 * one.abs().max()
+    assert bat3.shape == one[:4].shape and (bat3 - one[:4]).abs().max() <= 1e-10 * one.abs().max()
     # ragged sites through the same batched plan: each row must match a plan of that site's own size
     sizes = [600, 433, 600, 128, 57]
     rag = fit_sites(GPPlan("loadest", n, d, device=dev, lookahead=1, batch=4), [x[:k] for (x, _), k in zip(data, sizes)],
