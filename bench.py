@@ -468,6 +468,11 @@ def run_configs(dev, lib, quick):
     out["C2_loadest_n8192_engine"] = engine_iteration("loadest", 8192, 4 if quick else 20)
     out["C3_rating_n16384_f32"] = time_config("rating-gp kernel, n=16384 d=2 fp32 exact GP, one site", "rating", 16384, 2,
                                               "f32", 1, 3 if quick else 8, 2, dev, lib)
+    # the headline batch in the reference's ONLY dtype (engines/gpytorch.py:221-222): not a BASELINE config (those fix fp64 for
+    # config 2), reported because a user of the reference would run exactly this
+    out["C2_batch_32x8192_f32"] = time_config("32 independent loadest sites of n=8192 d=3 fp32 in one batched plan (the headline batch in the "
+                                              "reference's dtype; with the fp64 refinement of alpha)", "loadest", 8192, 3, "f32", 32,
+                                              3 if quick else 6, 2, dev, lib, probe=False)
     out["C4_share_64x4096_f64"] = time_config("64 independent loadest sites of n=4096 d=3 fp64 in one batched plan "
                                               "(BASELINE config 4's per-GPU share of 512 sites / 8 GPUs)", "loadest",
                                               4096, 3, "f64", 64, 3 if quick else 8, 2, dev, lib)
