@@ -140,7 +140,7 @@ __device__ __forceinline__ void yield_refresh(const unsigned* word, unsigned lds
 __device__ __forceinline__ void yield_if_asked(const unsigned* word, unsigned me, unsigned seen) {
   unsigned t, cnt;
   asm volatile(
-      "s_cmp_lg_u32 %5, %3\n\t"
+      "s_cmp_lg_u32 %4, %3\n\t"
       "s_cbranch_scc1 Lyield_done%=\n\t"
       "s_movk_i32 %1, 96\n"
       "Lyield_loop%=:\n\t"
@@ -154,7 +154,7 @@ __device__ __forceinline__ void yield_if_asked(const unsigned* word, unsigned me
       "s_cbranch_scc1 Lyield_loop%=\n"
       "Lyield_done%=:"
       : "=&s"(t), "=&s"(cnt)
-      : "s"(word), "s"(me), "s"(0), "s"(seen)
+      : "s"(word), "s"(me), "s"(seen)
       : "memory", "scc");
 }
 
