@@ -3,7 +3,7 @@
 discontinuum_amd/libdgp_hip_log.so: see the end of this docstring) logs, per 128-column block, the 100 MHz wall clock at
 the workgroup's first and last instruction and the CU it ran on.  Run under `rocprofv3 --kernel-trace`: the profiler's
 duration of the same launch minus the in-kernel span is the time the launch waited to be placed.
-  run:      rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 scripts/diag_in_situ.py run MODEL N DTYPE LOG.json
+  run:      rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 scripts/diag_in_situ.py run MODEL N DTYPE LOG.json [SITES]
   combine:  python3 scripts/diag_in_situ.py combine OUT/.../*_kernel_trace.csv LOG.json
   build:    for f in dgp_gram dgp_chol dgp_api dgp_dist dgp_selftest: hipcc <Makefile flags> -DDGP_DIAG_LOG -c f.hip; link -> libdgp_hip_log.so"""
 import csv
@@ -25,15 +25,19 @@ if sys.argv[1] == "run":
     from discontinuum_amd.backend import GPPlan
 
     model, n, dtn, out = sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    S = int(sys.argv[6]) if len(sys.argv) > 6 else 1  # sites in the plan (the log is site 0's workgroup)
     dt = torch.float64 if dtn == "f64" else torch.float32
     d = 3 if model == "loadest" else 2
     dev = torch.device("cuda:0")
-    X, r, noise, theta = bench.site(model, n, d, 0)
-    p = GPPlan(model, n, d, dtype=dt, device=dev)
-    p.set_inputs(torch.tensor(X, dtype=dt, device=dev).contiguous())
-    rd, nd = torch.tensor(r, dtype=dt, device=dev), torch.tensor(noise, dtype=dt, device=dev)
+    if S > 1:
+        p, theta, rd, nd = bench.make_plan(model, n, d, dt, dev, S, 1)
+    else:
+        X, r, noise, theta = bench.site(model, n, d, 0)
+        p = GPPlan(model, n, d, dtype=dt, device=dev)
+        p.set_inputs(torch.tensor(X, dtype=dt, device=dev).contiguous())
+        rd, nd = torch.tensor(r, dtype=dt, device=dev), torch.tensor(noise, dtype=dt, device=dev)
     for _ in range(4):
-        o = p.fit_step(theta, rd, nd)[0]
+        o = p.fit_step(theta, rd, nd)[0].reshape(-1)
     torch.cuda.synchronize()
     lib = _lib.load()
     lib.dgp_debug_diag_log.restype = C.c_int
