@@ -293,6 +293,12 @@ def time_config(name, model, n, d, dtype_name, S, steps, warmup, dev, lib, level
     ok = bool((host[:, lib.OUT_INFO] == 0).all()) and bool(torch.isfinite(host[:, lib.OUT_NLL]).all())
     rep = stage_report(plan, S, dtype_name, level, lib)
     N = plan.N
+    parity = None
+    if S > 1:  # site 0 of the batch against a single-site plan on the same inputs (batch_parity)
+        one, th1, r1, nz1 = make_plan(model, n, d, dt, dev, 1, 2)
+        parity = batch_parity(plan.fit_step(th, r, noise), one.fit_step(th1, r1, nz1), plan.ntheta, dtype_name, lib)
+        ok = ok and parity["ok"]
+        del one
     clk = None
     if probe:  # shader clock while the dominant kernel's stage runs back to back (after the timed steps)
         if rep["dominant"] == "lauum_kernel":
@@ -302,7 +308,7 @@ def time_config(name, model, n, d, dtype_name, S, steps, warmup, dev, lib, level
     res = {"workload": name, "kernel": f"{model}-gp", "n": n, "d": d, "dtype": dtype_name, "sites_in_plan": S, "steps": steps,
            "ms_per_step": dtm * 1e3, "fits_per_s": S / dtm, "tflops": S * float(N) ** 3 / dtm / 1e12,
            "frac_of_peak": S * float(N) ** 3 / dtm / 1e12 / PEAK_TFLOPS[dtype_name], "ok": ok,
-           "nll_site0": float(host[0, lib.OUT_NLL]), "hbm_gib": plan._ws.numel() / 2 ** 30, "lookahead": level,
+           "nll_site0": float(host[0, lib.OUT_NLL]), "hbm_gib": plan._ws.numel() / 2 ** 30, "lookahead": level, "parity": parity,
            "roofline": {"bound": "mfma", "kernel": rep["dominant"], "achieved": rep["achieved"], "peak": rep["peak"],
                         "unit": "TFLOP/s", "frac": rep["frac"], "ms_per_step": rep["ms"],
                         "clock_mhz": clk["mhz"] if clk else None,
@@ -540,6 +546,62 @@ class GpuStateSampler:
                 "source": "rocm-smi --showclocks --showpower, every ~0.25 s during the timed region"}
 
 
+# |batched - single| / scale bounds of `config.parity`.  fp64: both plans run the same k-ordered fma chains per element, the
+# observed difference is 0 or a few ulp; 1e-11 / 1e-9 are SURVEY 8d's oracle tolerances divided by 10.  fp32: both plans
+# refine alpha against the fp64-evaluated matrix, what differs is the rounding of two differently grouped factorisations:
+# tests/test_gpu_fp32.py's batched-vs-single bounds.
+PARITY_TOL = {"f64": {"nll_rel": 1e-11, "grad_rel": 1e-9, "alpha_rel": 1e-9, "dnoise_rel": 1e-9},
+              "f32": {"nll_rel": 2e-5, "grad_rel": 5e-4, "alpha_rel": 5e-5, "dnoise_rel": 5e-4}}
+
+
+def batch_parity(batched, single, ntheta, dtype_name, lib):
+    """Site 0 of a batched plan's fit step against a single-site plan's on the same inputs -> relative differences of the
+    NLL, the hyperparameter gradient, alpha = dNLL/dr and dNLL/dnoise (max-norm over max-norm), with the bounds and `ok`."""
+    (ob, ab, nb), (o1, a1, n1) = batched, single
+    ob, o1 = ob[0].cpu().double(), o1.cpu().double()
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max().clamp_min(1e-300))  # noqa: E731
+    g = slice(lib.OUT_DTHETA, lib.OUT_DTHETA + ntheta)
+    res = {"nll_rel": abs(float(ob[lib.OUT_NLL] - o1[lib.OUT_NLL])) / abs(float(o1[lib.OUT_NLL])),
+           "grad_rel": rel(ob[g], o1[g]), "alpha_rel": rel(ab[0].cpu().double(), a1.cpu().double()),
+           "dnoise_rel": rel(nb[0].cpu().double(), n1.cpu().double()),
+           "info": [int(ob[lib.OUT_INFO]), int(o1[lib.OUT_INFO])]}
+    tol = PARITY_TOL[dtype_name]
+    res["ok"] = bool(res["info"] == [0, 0] and all(res[k] <= tol[k] for k in tol))
+    res["tol"] = tol
+    res["against"] = "a single-site plan (lookahead 2) on site 0's inputs, same seed; after the timed region"
+    return res
+
+
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)
+    as a CHILD process, hand its stdout through unchanged (rank 0's one JSON line) and return its exit code.  Called before
+    anything in this process has touched the GPU (no torch.cuda call, no plan, no sampler); nothing is exec'ed.  A child
+    that dies leaves its exit code and the tail of its stderr on this process's stderr."""
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_ranks) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    with tempfile.TemporaryFile(mode="w+") as err:
+        run = subprocess.run(cmd, env=env, stderr=err)
+        err.seek(0)
+        text = err.read()
+    if run.returncode != 0:
+        sys.stderr.write(text[-6000:])
+        sys.stderr.write(f"\nbench.py: the {n_ranks}-rank child ({' '.join(cmd[1:4])} ...) exited with code {run.returncode}\n")
+    else:
+        sys.stderr.write(text[-2000:])
+    return run.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -571,12 +633,15 @@ def main():
     model = args.model
     d = args.d if args.d is not None else (3 if model == "loadest" else 2)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks and never touches the GPU
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     sampler = GpuStateSampler() if (rank == 0 and args.config == 2 and not args.roofline_only) else None
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launched by something else with a different rank count")
     dist = None
     # DGP_DIST_FORCE_COLLECTIVES=1: a ONE-rank run still creates its communicator and issues every collective (a
     # world-1 RCCL communicator is legal) -- the only way the RCCL entry points can execute on a one-GPU box
@@ -685,6 +750,15 @@ def main():
         clk_trtri = clock_probe(_lib.load(), dev, bplan.stage_trtri, max(1e-4, rep["stages_ms"]["trtri"] * 1e-3))
         torch.cuda.synchronize()
 
+    # ---- the headline CONFIGURATION under parity (rank 0): site 0 of the batched plan (hyperparameters of > 8 sites through
+    # device scratch, default tile selectors) against the single-site plan built from the same seed -- a different schedule
+    # (pairs + split chain + early inverse against groups of 4), different launches, the same matrix.  Asserted: the line is
+    # only printed if the batch the value was measured on reproduces the single-site result.
+    parity = None
+    if rank == 0 and S > 1:
+        parity = batch_parity(bplan.fit_step(btheta, ball, bnoise), plan.fit_step(theta, y0, noise0), plan.ntheta, args.dtype, _lib)
+        assert parity["ok"], f"site 0 of the {S}-site batch differs from the single-site plan: {parity}"
+
     # ---- single-site loop on rank 0: latency of one fit alone on the GPU
     single_ms = None
     if rank == 0:
@@ -755,7 +829,7 @@ def main():
             "config": {"workload": f"synthetic {model}-gp kernel, n={n} d={d} {args.dtype} exact GP, "
                                    f"{S} independent site(s) per GPU in one batched plan (one step = one fit of each)",
                        "n": n, "d": d, "sites_per_gpu": S, "fits_per_step": world * S,
-                       "lookahead": not args.no_lookahead, "nll_site0": float(host[0, _lib.OUT_NLL])},
+                       "lookahead": not args.no_lookahead, "nll_site0": float(host[0, _lib.OUT_NLL]), "parity": parity},
             "gpu_state": sampler.window(wall0, wall1) if sampler is not None else None,
             "single_site": {"fits_per_s": 1e3 / single_ms, "ms_per_fit": single_ms,
                             "tflops": float(N) ** 3 / (single_ms * 1e-3) / 1e12,

@@ -75,6 +75,7 @@ SIGNATURES = {
     "dgp_dist_grad_partial": (_i, [_vp, _dp, _vp, _vp, _vp, _vp]),
     "dgp_dist_slab": (_i, [_vp, _i, C.POINTER(_vp)]),
     "dgp_plan_buffer": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i64)]),
+    "dgp_plan_site_stride_bytes": (_sz, [_vp]),
     "dgp_set_inputs": (_i, [_vp, _vp, _vp]),
     "dgp_fit_step": (_i, [_vp, _dp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgp_factorize": (_i, [_vp, _dp, _vp, _vp, _vp, _vp]),

@@ -113,12 +113,14 @@ class GPPlan:
         if not (torch.is_tensor(t) and t.is_cuda and t.dtype == self.dtype and t.is_contiguous() and t.numel() == length):
             raise ValueError(f"{name} must be a contiguous {self.dtype} CUDA tensor with {length} elements")
 
-    def buffer(self, which: int) -> torch.Tensor:
-        """Tensor view of a plan buffer (tests / profiling)."""
+    def buffer(self, which: int, site: int = 0) -> torch.Tensor:
+        """Tensor view of a plan buffer (tests / profiling); ``site``: which site's copy of a batched plan."""
         p, ld = C.c_void_p(), C.c_int64()
         _lib.check(self.lib.dgp_plan_buffer(self._h, which, C.byref(p), C.byref(ld)), "dgp_plan_buffer")
+        if not 0 <= site < self.batch:
+            raise ValueError(f"site must be in 0..{self.batch - 1}")
         esz = torch.empty((), dtype=self.dtype).element_size()
-        off = p.value - self._ws.data_ptr()
+        off = p.value - self._ws.data_ptr() + site * int(self.lib.dgp_plan_site_stride_bytes(self._h))
         N = self.N
         count = {_lib.BUF_XT: self.d * N, _lib.BUF_Z: N, _lib.BUF_ALPHA: N}.get(which, N * N)
         flat = self._ws[off:off + count * esz].view(self.dtype)

@@ -341,6 +341,8 @@ int dgp_plan_set_lookahead(dgp_plan* p, int level) {
   return 0;
 }
 
+size_t dgp_plan_site_stride_bytes(const dgp_plan* p) { return p ? layout(p).total : 0; }
+
 int dgp_plan_buffer(const dgp_plan* p, int which, void** dev_ptr, int64_t* ld) {
   if (!p || !dev_ptr || !p->ws) return fail(DGP_E_ARG, "dgp_plan_buffer: null / no workspace");
   void* q = nullptr;

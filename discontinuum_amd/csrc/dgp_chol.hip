@@ -43,8 +43,8 @@ struct Prefetch {
 // batch's are thousands, and a GPU full of polling workgroups leaves the producer no slot (measured: every wait ran into its
 // bound, profiles/r04_experiments_batched_split.txt) -- batched plans never poll (split_applies: B == 1).  So every wait
 // is BOUNDED: after CHAIN_WAIT_TICKS of the 100 MHz wall clock (2 s -- a whole n = 8192 fit takes 12 ms) the waiter
-// writes DGP_INFO_CHAIN_TIMEOUT into info[0] and its workgroup returns without touching the matrix; every later waiter
-// sees the code and returns at once, so the chain drains in about one budget, the result row carries info < 0 and a NaN
+// writes DGP_INFO_CHAIN_TIMEOUT into info[0] (unless a pivot index is already there), sets info[CHAIN_ABORT] and its workgroup
+// returns without touching the matrix; every later waiter sees the abort word and returns at once, so the chain drains in about one budget, the result row carries info < 0 and a NaN
 // NLL (finish_kernel) instead of the device hanging.
 #define DGP_INFO_CHAIN_TIMEOUT (-7)
 #define CHAIN_WAIT_TICKS 200000000LL
@@ -59,12 +59,15 @@ __device__ __forceinline__ bool chain_wait(const int* w0, int v0, const int* w1,
     if (!(chain_reached(w0, v0) && (w1 == nullptr || chain_reached(w1, v1)))) {
       const long long t0 = wall_clock64();
       while (!(chain_reached(w0, v0) && (w1 == nullptr || chain_reached(w1, v1)))) {
-        if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == DGP_INFO_CHAIN_TIMEOUT) {
+        if (__hip_atomic_load(info + CHAIN_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {  // a wait ran out elsewhere
           ok = 0;
           break;
         }
         if (wall_clock64() - t0 > CHAIN_WAIT_TICKS) {
-          __hip_atomic_store(info, DGP_INFO_CHAIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // the code goes only into an EMPTY slot: a pivot index that diag(k) has already published (info > 0, what the
+          // caller's jitter ladder / NaN policy keys on) survives; the abort word makes every later waiter leave at once
+          atomicCAS(info, 0, DGP_INFO_CHAIN_TIMEOUT);
+          __hip_atomic_store(info + CHAIN_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = 0;
           break;
         }
@@ -246,17 +249,22 @@ __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_col1
 // the trailing updates sum from zero (dgp_gemm.h::trailing_begin) the fp64 block changes neither the log-determinant
 // nor the quadratic form's error (which is then set by L being STORED in fp32), and costs 2 % (n = 16384) to 12 %
 // (n = 2048) of a fit step.  Kept as a measurement knob.
-// true the first time it is asked on the calling thread's current device (a per-device "configured" flag)
+// Runs `configure` once per device (the calling thread's current one) UNDER the lock and marks the device configured only
+// when it returned hipSuccess: a second host thread that drives the same device (thread ranks, two Python threads with a
+// plan each) either finds the opt-in done or waits for it -- it can never launch with > 64 KB of dynamic LDS before the
+// attribute is set (with the flag set first and the call outside the lock it could).  -> configure's error, else hipSuccess.
 struct DeviceOnce {
   std::mutex mtx;
   bool seen[64] = {false};
-  bool first() {
+  template <typename F>
+  hipError_t run(F&& configure) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown: configure every time (cheap)
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return configure();  // unknown: configure every time (cheap)
     std::lock_guard<std::mutex> lock(mtx);
-    const bool f = !seen[dev];
-    seen[dev] = true;
-    return f;
+    if (seen[dev]) return hipSuccess;
+    const hipError_t e = configure();
+    if (e == hipSuccess) seen[dev] = true;
+    return e;
   }
 };
 static bool f32_diag64() {
@@ -278,7 +286,7 @@ static void launch_bulk(T* A, long N, int k, int nk, int jbeg, const SyrkShape& 
   // panel of a pair at n = 8192: trsm 59 -> 33 us, column update 77 -> 30).  Measured (step, ms): n = 6144 6.72 -> 6.69,
   // 8192 11.93 -> 11.89, 12288 33.3 -> 32.7, 16384 fp64 71.6 -> 70.9, 16384 fp32 38.95 -> 38.55; n >= 24576 (bound by the
   // bulk launches) and n <= 4096 (one round of tiles anyway): nothing or slightly worse -- hence the window.
-  static const int pad_env = getenv("DGP_BULK_LDS_PAD") ? atoi(getenv("DGP_BULK_LDS_PAD")) : 14336;
+  static const int pad_env = getenv("DGP_BULK_LDS_PAD") ? std::min(16384, std::max(0, atoi(getenv("DGP_BULK_LDS_PAD")))) : 14336;
   // (batched plans: 64 x 4096 797 -> 789 fits/s, 32 x 8192 115.6 -> 115.0, 128 x 2048 no change -- their chain kernels are wide enough)
   const size_t pad = (bt.B == 1 && nbk >= 40 && nbk <= 160) ? (size_t)pad_env : 0;
   if (yields(bt))
@@ -294,9 +302,11 @@ static void launch_diag_as(TS* A, long N, long k0, TS* Tinv, TS* logdet, int* in
   // process that drives plans on several GPUs opts in on each (a failure surfaces as the launch error below it)
   const size_t bytes = potrf_diag_fast_smem<TC>();
   static DeviceOnce configured;
-  if (configured.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_fast_kernel<TS, TC>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  // (a failed opt-in is retried by the next call and surfaces here as the launch error: invalid value for > 64 KB)
+  (void)configured.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_fast_kernel<TS, TC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  });
   potrf_diag_fast_kernel<TS, TC><<<dim3(1, 1, (unsigned)bt.B), 256, bytes, s>>>(
       A, N, k0, Tinv, logdet, info, bt.ws, bt.ws * (long)sizeof(TS) / (long)sizeof(int), init ? 1 : 0, POTRF_INFO_INTS, logdet_hi,
       done_index, done_value, yields(bt) ? CHAIN_YIELD : -1);
@@ -642,8 +652,10 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
   hipEvent_t* U = ev + 2 * nbk;   // bulk(q) done, on s2
   const size_t cbytes = crit_smem_bytes<T>();
   static DeviceOnce configured;  // one per instantiation (T), keyed by device
-  if (configured.first()) {
-    const hipError_t ce = hipFuncSetAttribute(reinterpret_cast<const void*>(&crit_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbytes);
+  {
+    const hipError_t ce = configured.run([&] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(&crit_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cbytes);
+    });
     if (ce != hipSuccess) return (int)ce;
   }
   int ck_next = 0;

@@ -111,7 +111,8 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready_blocks, TrtriProgre
 #define CHAIN_FLAG0 2  /* info[2], info[3]: the split chain's progress counters (rest steps / bulk launches finished) */
 #define EARLY_CTR0 4
 #define EARLY_CTR_PAIRS 125
-#define POTRF_INFO_INTS (EARLY_CTR0 + 2 * EARLY_CTR_PAIRS + 3)
+#define POTRF_INFO_INTS (EARLY_CTR0 + 2 * EARLY_CTR_PAIRS + 4)
+#define CHAIN_ABORT (POTRF_INFO_INTS - 4)      /* != 0: a bounded wait of the split chain ran out -- every later waiter leaves at once */
 #define CHAIN_YIELD (POTRF_INFO_INTS - 3)      /* cu_code() of the running diagonal-block kernel, else 0 (dgp_common.h: yield_if_asked) */
 #define CHAIN_DIAG_DONE (POTRF_INFO_INTS - 2)  /* diagonal blocks finished (split chain: the rest stream's trsm waits on it) */
 #define CHAIN_TICKET (POTRF_INFO_INTS - 1)     /* workgroup ticket of the rest stream's column-update kernel */

@@ -20,8 +20,14 @@ every model holds its fitted parameters and is ready for ``predict``.  Both mode
 forward -- done here once per iteration on the stacked parameters -- and a learned homoskedastic noise term).
 Early stopping is per site; the rating-gp monotonicity penalty (``monotonic_penalty_weight``) differentiates every
 site's posterior mean at its own random grid through ONE batched ``dgp_predict_mean`` / ``dgp_mean_vjp`` per iteration;
-``return_state=True`` / ``resume=state`` continue a run where it stopped (optimiser moments, schedules, counters).
-Not supported here: arbitrary penalty callbacks.
+``return_state=True`` / ``resume=state`` continue a run where it stopped (optimiser moments, schedules, counters);
+``penalty_callback`` / ``penalty_weight`` add the reference's generic penalty term per site (``:362-373``).
+
+Across the GPUs of a node: ``fit_many_distributed`` -- site i trains on rank i mod G (``sites.site_partition``), every rank
+runs ``fit_many`` on its share on its own GPU, and ONE collective at the end of the fit (an ``all_gather`` of the fitted raw
+parameters, final objectives, iteration counts and stop reasons; RCCL over xGMI, gloo in the CPU tests) hands every rank
+the whole table, so any rank can ``predict`` any site.  No per-iteration traffic ("or only at the end
+of the fit"); the reference's fan-out is ``examples/nwqn-loadest-example/nwqn-loadest-example.py:38-125, 156-159``.
 """
 from __future__ import annotations
 
@@ -150,6 +156,15 @@ class FitManyState:
         return cls(**{k: d[k] for k in cls.FIELDS if k in d})
 
 
+def _fresh_seeded(m, tx, ty, tu, seed):
+    """``m._fresh_model`` -- under its own seed when one is given (the global RNG is left where it was)."""
+    if seed is None:
+        return m._fresh_model(tx, ty, tu)
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(int(seed))
+        return m._fresh_model(tx, ty, tu)
+
+
 def _per_site_clip(raw_grads: dict, B: int, max_norm: float = 1.0):
     """``clip_grad_norm_(max_norm)`` followed by the reference's NaN scan (engines/gpytorch.py:387-400), per site, on
     stacked gradients (leading dimension B).  The norm is taken of the RAW gradient, like the reference and
@@ -168,7 +183,8 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
              scheduler: bool = True, progress: bool = False, early_stopping: bool = False,
              monotonic_penalty_weight: float = 0.0, grid_size: int = 64, monotonic_penalty_interval: int = 1,
              resume: FitManyState | None = None, return_state: bool = False, generator: torch.Generator | None = None,
-             optimizer: str = "adam", penalty_callback=None, penalty_weight: float = 0.0, _penalty_uniforms=None):
+             optimizer: str = "adam", penalty_callback=None, penalty_weight: float = 0.0, site_seeds=None,
+             _penalty_uniforms=None):
     """Fit ``models[i]`` to ``datasets[i] = (covariates, target[, target_unc])`` for all i at once.  Returns the
     per-site final objectives (a float64 tensor) -- with ``return_state=True`` the pair (objectives, ``FitManyState``);
     the models are updated in place (``is_fitted``, parameters, device state).
@@ -187,7 +203,14 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     ``penalty_callback(site_index, params)`` with ``params`` = {name: that site's raw parameter tensor}, names as in
     ``models[i].model.named_parameters()`` prefixed with ``model.`` (likelihood parameters: ``likelihood.``), each a
     differentiable view -- it returns a scalar tensor (anything torch can differentiate w.r.t. those tensors).  Same
-    tolerance as the reference: an exception or a non-tensor result drops the term for that site and iteration."""
+    tolerance as the reference: an exception or a non-tensor result drops the term for that site and iteration.
+
+    ``site_seeds`` (one int per site): site b's model is built under ``torch.manual_seed(site_seeds[b])`` (inside a forked
+    RNG scope) -- the rating-gp power law and gate start from random draws like the reference's
+    (src/rating_gp/models/gpytorch.py:30-33, kernels.py:276), so without seeds a site's trajectory depends on how many
+    sites were built before it; with them it depends on the site alone (``fit_many_distributed`` relies on that)."""
+    if site_seeds is not None and len(site_seeds) != len(models):
+        raise ValueError("site_seeds needs one seed per model")
     if optimizer not in ("adam", "adamw"):
         raise ValueError(f"Unsupported optimizer: {optimizer!r}. Supported optimizers are 'adam' and 'adamw'.")
     if len(models) != len(datasets) or not models:
@@ -198,7 +221,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     for m, record in zip(models, datasets):
         cov, tgt, unc = (tuple(record) + (None,))[:3]
         tx, ty, tu = m._attach(cov, tgt, unc)
-        m._fresh_model(tx, ty, tu)
+        _fresh_seeded(m, tx, ty, tu, None if site_seeds is None else site_seeds[len(xs)])
         m.model.train()
         m.likelihood.train()
         xs.append(tx)
@@ -415,22 +438,139 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
             break
 
     # ---- hand the fitted parameters back to the per-site models
-    with torch.no_grad():
-        for b, (m, own) in enumerate(zip(models, own_params)):
-            for k, v in params.items():
-                own[k].copy_(v[b])
-            m._current_iteration = int(last_iteration[b])
-            m._pending_device = (xs[b], ys[b])  # the site's own plan is created when it first predicts
-            m._plan, m._factor_key = None, None
-            m.model.eval()
-            m.likelihood.eval()
-            m.is_fitted = True
+    for b, (m, own) in enumerate(zip(models, own_params)):
+        _hand_back(m, own, {k: v[b] for k, v in params.items()}, int(last_iteration[b]), xs[b], ys[b])
     if return_state:
         state = FitManyState(params={k: v.detach().clone() for k, v in params.items()}, m1=m1, m2=m2, step=step, lr=lr, best=best,
                              num_bad=num_bad, cooldown=cooldown, es_best=es_best, stale=stale, live=live, last_obj=last_obj,
                              last_iteration=last_iteration, iterations_done=torch.tensor(it0 + iterations), nan_run=nan_run)
         return last_obj, state
     return last_obj
+
+
+def _hand_back(m, own, values, last_iteration, tx, ty):
+    """Fitted raw parameters ``values`` ({name: tensor}) -> the model object ``m`` (``own`` = its ``_HostSide``'s
+    ``named_parameters()``); afterwards ``m`` is what ``m.fit`` leaves behind: ready for ``predict``."""
+    with torch.no_grad():
+        for k, v in values.items():
+            own[k].copy_(v.reshape(own[k].shape))
+    m._current_iteration = int(last_iteration)
+    m._pending_device = (tx, ty)  # the site's own plan is created when it first predicts
+    m._plan, m._factor_key = None, None
+    m.model.eval()
+    m.likelihood.eval()
+    m.is_fitted = True
+
+
+# stop reasons in the gathered table of fit_many_distributed
+STOP_BUDGET, STOP_EARLY, STOP_FAILED = 0.0, 1.0, 2.0
+
+
+def fit_many_distributed(models, datasets, group=None, load: str = "all", seed: int | None = 0, **kw):
+    """``fit_many`` over the ranks of a ``torch.distributed`` process group (one rank per GPU).
+
+    Every rank passes the SAME ``models`` / ``datasets`` lists (like the reference's ``iterdata`` list,
+    ``examples/nwqn-loadest-example/nwqn-loadest-example.py:149-159``).  Site i belongs to rank i mod world
+    (``sites.site_partition``); each rank trains its share with ``fit_many(share, **kw)`` on its own device; then ONE
+    collective -- an ``all_gather`` of a zero-padded float64 table with one row per site,
+
+        [ raw parameters flattened in ``named_parameters()`` order (P_raw) | final objective | iterations run | stop reason ]
+
+    (stop reason: 0 iteration budget used up, 1 early stopping, 2 the rank's ``fit_many`` raised) -- gives every rank the
+    result of every site.  ``load``: "all" (default) -- every rank loads every site's parameters into its model objects, so
+    ``predict`` / ``predict_many`` work anywhere; "rank0" -- only rank 0 loads the sites it does not own; "own" -- nobody
+    does (the table is still returned everywhere).  There is no per-iteration traffic and no data-path collective.
+
+    A rank whose ``fit_many`` raises (e.g. more than 10 consecutive NaN objectives at one of its sites,
+    ``engines/gpytorch.py:356-357``) still takes part in the collective -- its rows carry stop reason 2 and NaN -- and the
+    error is then raised on EVERY rank, so no rank is left waiting in the gather.
+
+    ``seed`` (default 0; None: unseeded): site i's model is built under ``torch.manual_seed(seed + i)`` (``fit_many``'s
+    ``site_seeds``), so the result of a site does not depend on the number of ranks or on which rank trained it -- a
+    single-process ``fit_many(..., site_seeds=[seed + i ...])`` gives the same bits.
+
+    Without an initialised process group (or world 1) this is ``fit_many`` plus the table.  ``resume`` / ``return_state``
+    are per-rank notions and not supported here.  Returns ``(objectives (n_sites,), table (n_sites, P_raw + 3))``, float64,
+    identical on every rank."""
+    import torch.distributed as dist
+
+    from .sites import gather_site_results, site_partition
+
+    if load not in ("all", "rank0", "own"):
+        raise ValueError("load must be 'all', 'rank0' or 'own'")
+    if "resume" in kw or kw.get("return_state") or "site_seeds" in kw:
+        raise ValueError("fit_many_distributed: resume / return_state are per-rank; use fit_many on each rank's share")
+    if len(models) != len(datasets) or not models:
+        raise ValueError("fit_many_distributed needs one (covariates, target) pair per model")
+    n_sites = len(models)
+    active = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if active else 1
+    rank = dist.get_rank(group) if active else 0
+    mine = site_partition(n_sites, world, rank)
+
+    error = None
+    objs = state = None
+    if mine:
+        try:
+            objs, state = fit_many([models[i] for i in mine], [datasets[i] for i in mine], return_state=True,
+                                   site_seeds=None if seed is None else [seed + i for i in mine], **kw)
+        except Exception as e:  # noqa: BLE001 -- reported after the collective, on every rank
+            error = e
+
+    # the row layout is a property of the model family: take it from a site this rank has walked, else walk site 0
+    def tree(m, record):
+        cov, tgt, unc = (tuple(record) + (None,))[:3]
+        tx, ty, tu = m._attach(cov, tgt, unc)
+        _fresh_seeded(m, tx, ty, tu, 0)  # values are overwritten below; seeded so that the global RNG is not consumed
+        return _HostSide(m.model, m.likelihood, tx.shape[1]), tx, ty
+
+    if state is not None:
+        names = list(state.params)
+        widths = [int(state.params[k][0].numel()) for k in names]
+    else:
+        host, _, _ = tree(models[0], datasets[0])  # (a rank without sites, or one whose fit raised)
+        shapes = dict(host.named_parameters())
+        names = list(shapes)
+        widths = [int(shapes[k].numel()) for k in names]
+    P = sum(widths)
+    local = torch.full((len(mine), P + 3), float("nan"), dtype=torch.float64)
+    if state is not None:
+        flat = torch.cat([state.params[k].detach().reshape(len(mine), -1).to(torch.float64) for k in names], dim=1)
+        local[:, :P] = flat
+        local[:, P] = objs
+        local[:, P + 1] = (state.last_iteration + 1).to(torch.float64)
+        local[:, P + 2] = torch.where(state.live, torch.full((len(mine),), STOP_BUDGET, dtype=torch.float64),
+                                      torch.full((len(mine),), STOP_EARLY, dtype=torch.float64))
+    else:
+        local[:, P + 2] = STOP_FAILED
+    if active and world > 1:
+        on_device = dist.get_backend(group) == "nccl"  # RCCL moves device memory; gloo host memory
+        dev = torch.device(models[0].device) if on_device else torch.device("cpu")
+        table = gather_site_results(local.to(dev), n_sites, group).cpu()
+    else:
+        table = local
+    failed = torch.nonzero(table[:, P + 2] == STOP_FAILED).reshape(-1).tolist()
+    if failed:
+        who = sorted({i % world for i in failed})
+        raise RuntimeError(f"fit_many_distributed: fit_many failed on rank(s) {who} (sites {failed[:8]}"
+                           f"{' ...' if len(failed) > 8 else ''})" + (f": {error}" if error is not None else "")) from error
+
+    # ---- every site's result into the model objects of the ranks that want it
+    if load == "all" or (load == "rank0" and rank == 0):
+        owned = set(mine)
+        for i in range(n_sites):
+            if i in owned:
+                continue  # fit_many has already handed these back, bitwise the gathered values
+            host, tx, ty = tree(models[i], datasets[i])
+            own = dict(host.named_parameters())
+            if list(own) != names:
+                raise ValueError(f"site {i}: parameter tree differs from the gathered table's (one model family per call)")
+            values, o = {}, 0
+            for k, w in zip(names, widths):
+                values[k] = table[i, o:o + w].to(own[k].dtype)
+                o += w
+            _hand_back(models[i], own, values, int(table[i, P + 1]) - 1, tx, ty)
+    return table[:, P].clone(), table
 
 
 def predict_many(models, covariates_list):
@@ -506,4 +646,4 @@ def predict_many(models, covariates_list):
     return results
 
 
-__all__ = ["fit_many", "predict_many", "FitManyState"]
+__all__ = ["fit_many", "fit_many_distributed", "predict_many", "FitManyState"]

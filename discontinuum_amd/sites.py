@@ -42,13 +42,23 @@ def gather_site_results(local: torch.Tensor, n_sites: int, group=None) -> torch.
     return out
 
 
+def _side_stream(plan):
+    """ONE side stream per plan object, created at first use and kept: the library keys a process-lifetime set of
+    internal streams (bulk / rest / early) on every caller stream it sees (csrc/dgp_api.hip::stream_set), and a process has
+    few hardware queues -- fresh streams per call would walk torch's pool of 32 and leave up to 32 such sets behind."""
+    st = getattr(plan, "_side_stream", None)
+    if st is None:
+        st = plan._side_stream = torch.cuda.Stream(device=plan.device)
+    return st
+
+
 def _fit_sites_batched_plans(plans, Xs, rs, noises, theta):
     """Several batched plans, each with a contiguous share of the sites on its own stream; rows come back in input order."""
     dev = plans[0].device
     share = -(-len(Xs) // len(plans))
     ready = torch.cuda.Event()
     ready.record()  # inputs were produced on the caller's stream
-    streams = [torch.cuda.Stream(device=dev) for _ in plans]
+    streams = [_side_stream(p) for p in plans]
     parts = []
     for k, (plan, st) in enumerate(zip(plans, streams)):
         lo, hi = k * share, min((k + 1) * share, len(Xs))
@@ -115,7 +125,7 @@ def fit_sites(plans, Xs, rs, noises, theta):
         for p in plans:
             if hasattr(p, "set_lookahead"):
                 p.set_lookahead(1)
-    streams = [torch.cuda.Stream(device=plans[0].device) for _ in plans] if on_gpu else [None] * len(plans)
+    streams = [_side_stream(p) for p in plans] if on_gpu else [None] * len(plans)
     if on_gpu:
         ready = torch.cuda.Event()
         ready.record()  # inputs were produced on the caller's stream

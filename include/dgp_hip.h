@@ -152,6 +152,8 @@ int dgp_plan_set_lookahead(dgp_plan* plan, int level);
 int dgp_plan_set_option(dgp_plan* plan, int key, int64_t value);
 int dgp_plan_get_option(const dgp_plan* plan, int key, int64_t* value_out);
 int dgp_plan_buffer(const dgp_plan* plan, int which, void** dev_ptr, int64_t* ld);
+/* batched plans: site b's copy of every dgp_plan_buffer buffer starts this many bytes after site b - 1's (tests) */
+size_t dgp_plan_site_stride_bytes(const dgp_plan* plan);
 
 /* Training inputs X (n x d row-major, device) -> internal SoA copy.  Replaces the train_x tensor
  * handed to ExactGP at engines/gpytorch.py:221-235. */

@@ -14,19 +14,40 @@ class OraclePlan:
     (fit loop, lowering, priors, constraints, checkpointing) can be exercised without a GPU; the product
     never constructs it (``MarginalHIP._plan_factory`` is ``GPPlan``)."""
 
-    def __init__(self, model, n, d, dtype=torch.float64, device="cpu", lookahead=True):
+    def __init__(self, model, n, d, dtype=torch.float64, device="cpu", lookahead=True, batch=1):
         self.model, self.n, self.d, self.dtype, self.device = model, n, d, dtype, torch.device("cpu")
         self.ntheta = orc.loadest_ntheta(d) if model == "loadest" else orc.RATING_NTHETA
         self.calls = 0
+        self.batch = int(batch)
+        # batch > 1 (``GPPlan(batch=B)``'s surface for ``fit_many``): one single-site double per site, ragged sizes
+        self._sites = [OraclePlan(model, n, d, dtype) for _ in range(self.batch)] if self.batch > 1 else None
+        self._sizes = [n] * self.batch
+
+    def set_site_sizes(self, sizes):
+        self._sizes = [int(v) for v in sizes]
 
     def set_inputs(self, X):
+        if self._sites:
+            for b, p in enumerate(self._sites):
+                p.n = self._sizes[b]
+                p.set_inputs(X[b, : self._sizes[b]])
+            return
         self.X = X.double()
 
     def set_dr_weights(self, w):
+        if self._sites:
+            for b, p in enumerate(self._sites):
+                p.set_dr_weights(None if w is None else w[b][:, : self._sizes[b]])
+            return
         self._dr_w = None if w is None else w.double()
 
     def fit_step(self, theta, r, noise):
         self.calls += 1
+        if self._sites:
+            rows = [p.fit_step(theta[b], r[b, : self._sizes[b]], noise[b, : self._sizes[b]]) for b, p in enumerate(self._sites)]
+            pad = lambda v: torch.cat([v, torch.zeros(self.n - v.shape[0], dtype=v.dtype)])  # noqa: E731
+            return (torch.stack([o for o, _, _ in rows]), torch.stack([pad(a) for _, a, _ in rows]),
+                    torch.stack([pad(g) for _, _, g in rows]))
         theta = torch.as_tensor(theta, dtype=torch.float64).detach()
         out = torch.zeros(_lib.OUT_LEN, dtype=self.dtype)
         try:
