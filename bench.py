@@ -322,11 +322,12 @@ def time_config(name, model, n, d, dtype_name, S, steps, warmup, dev, lib, level
     return res
 
 
-def engine_iteration(family, n, iters):
-    """BASELINE config 1 through the engine surface: ms per training iteration of `model.fit` (host loop + device step)."""
+def engine_site(family, n, seed=0):
+    """One synthetic sampling record as the ENGINE takes it (labelled arrays in data space, like the reference's fixtures
+    tests/test_loadest_gp.py:12-28) -> (Model class, (covariates, target), fit keyword arguments)."""
     from discontinuum_amd.xr_compat import DataArray, Dataset
 
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     if family == "loadest":
         from discontinuum_amd.loadest_gp import LoadestGP as Model
 
@@ -343,6 +344,54 @@ def engine_iteration(family, n, iters):
         q = np.exp(1.6 * np.log(stage) + 0.05 * rng.standard_normal(n))
         args = (Dataset({"stage": ("time", stage)}, coords={"time": t}), DataArray(q, dims=("time",), coords={"time": t}, name="q"))
         kw = {"target_unc": DataArray(np.full(n, 1.05), dims=("time",), coords={"time": t}, name="q_unc")}
+    return Model, args, kw
+
+
+def train_many(family, n, sites, iters, barrier=None, distributed=False):
+    """The product-level many-site path (discontinuum_amd/multisite_fit.py): TRAIN `sites` independent sites of n observations for
+    `iters` iterations -- one batched fit step + the vectorised host algebra + the reference's per-site optimiser semantics
+    (engines/gpytorch.py:346-451) per iteration -- through `fit_many` (one process) or `fit_many_distributed` (site i on rank
+    i mod world, ONE gather of the fitted parameters at the end of the fit).  Timed twice, with `iters` and with 2 iterations:
+    the difference is the steady-state iteration, the rest is set-up (model objects, pipelines, plan creation, upload).
+    -> dict with sites x iterations / s (whole call) and ms per iteration (steady state)."""
+    from discontinuum_amd import multisite_fit
+
+    def run(k):
+        models, data = [], []
+        for i in range(sites):
+            Model, args, kw = engine_site(family, n, seed=i)
+            models.append(Model())
+            data.append(args + ((kw["target_unc"],) if kw else ()))
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stderr(io.StringIO()):
+            if distributed:
+                objs, _ = multisite_fit.fit_many_distributed(models, data, iterations=k, load="rank0")
+            else:
+                objs = multisite_fit.fit_many(models, data, iterations=k)
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        return time.perf_counter() - t0, objs
+
+    short = min(2, iters)
+    run(short)  # warm-up: code objects, allocator
+    t_short, _ = run(short)
+    t_full, objs = run(iters)
+    per_it = (t_full - t_short) / (iters - short) if iters > short else t_full / max(1, iters)
+    return {"workload": f"{sites} {family}-gp sites of n={n} (d=2, fp64) trained for {iters} iterations by "
+                        f"{'fit_many_distributed' if distributed else 'fit_many'} (labelled arrays in, fitted models out)",
+            "sites": sites, "n": n, "iterations": iters, "seconds": t_full, "site_iterations_per_s": sites * iters / t_full,
+            "ms_per_iteration": per_it * 1e3, "site_iterations_per_s_steady": sites / per_it if per_it > 0 else None,
+            "setup_s": max(0.0, t_full - per_it * iters), "ok": bool(torch.isfinite(objs).all()),
+            "objective_mean": float(objs.mean())}
+
+
+def engine_iteration(family, n, iters):
+    """BASELINE config 1 through the engine surface: ms per training iteration of `model.fit` (host loop + device step)."""
+    Model, args, kw = engine_site(family, n)
     m = Model()
     with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):  # the progress bar
         m.fit(*args, iterations=5, **kw)
@@ -486,6 +535,10 @@ def run_configs(dev, lib, quick):
                                                       "gradient) on ONE GPU", "loadest", 65536, 3, "f32", 1, 2, 1, dev, lib,
                                                       probe=False)
     out["inference_from_n8192"] = inference_configs(dev, lib, quick)
+    # the product-level many-site path: whole training runs through fit_many (host algebra vmapped over sites + per-site
+    # Adam / plateau / clipping around ONE batched fit step per iteration)
+    out["fit_many_64x4096"] = train_many("loadest", 4096, 64, 6 if quick else 20)
+    out["fit_many_256x300"] = train_many("loadest", 300, 256, 20 if quick else 100)
     # last (it creates streams): config 4's share as two plans of 32 -- at this size a second plan hides part of the
     # first one's panel chain (scripts/c4_experiments.py: 82.5 -> 79.9 ms)
     out["C4_share_64x4096_f64"]["as_two_plans_of_32"] = split_batch_config("loadest", 4096, 3, "f64", (32, 32), 3 if quick else 8, 2,
@@ -626,6 +679,10 @@ def main():
                          "ranks (dist_chol.DistributedFit.fit_step; --size 65536 --dtype f32 is BASELINE config 5)")
     ap.add_argument("--group-panels", type=int, default=0,
                     help="--config 5: 128-wide panels per column group of the block-cyclic layout (0: DistributedFit's default)")
+    ap.add_argument("--train", type=int, default=0, metavar="K",
+                    help="after the step metric: TRAIN world x sites-per-gpu engine-level sites of --size observations for K "
+                         "iterations through multisite_fit.fit_many_distributed (each rank its share, one gather at the end); "
+                         "reported as `train` (sites x iterations / s) next to the step metric")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the per-kernel timing loop of the roofline object (the command profiled with "
                          "rocprofv3 --kernel-trace --stats for profiles/)")
@@ -666,10 +723,22 @@ def main():
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     if dist is not None:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # stdout carries ONE line, rank 0's JSON: communication libraries that print to file descriptor 1 while they connect
+        # (gloo: "[Gloo] Rank 0 is connected to ...") go to stderr -- for good on the other ranks
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()  # lazily created transports connect (and print) here, not under the timed region
+        finally:
+            sys.stdout.flush()
+            if rank == 0:
+                os.dup2(keep, 1)
+            os.close(keep)
 
     from discontinuum_amd import _lib
     from discontinuum_amd.backend import GPPlan
@@ -701,15 +770,26 @@ def main():
 
     bplan.set_timing(True)  # HIP events around every bulk launch, on the stream it runs on (the roofline object)
     if args.roofline_only:
+        # the command the profiler passes run (scripts/collect_profiles.sh): the SAME process prints what its own HIP events
+        # say about every step's lauum launch, so the tracer's durations can be compared with them launch by launch, and the
+        # shader clock the chip held under that kernel in THIS (profiled) process
+        lauum_ms = []
         for _ in range(max(3, args.steps)):
             batch_step()
+            lauum_ms.append(bplan.get_timing()[_lib.TIME_LAUUM])  # (synchronises on the step's events)
         torch.cuda.synchronize()
         ms = bplan.get_timing()
+        clk = None if args.no_clock_probe else clock_probe(_lib.load(), dev, bplan.stage_lauum, max(1e-4, ms[_lib.TIME_LAUUM] * 1e-3))
+        Nn = bplan.N
         print(json.dumps({"roofline_only": True, "kernel": "syrk_kernel", "launches": int(ms[_lib.TIME_SYRK_N]),
                           "ms_per_step": ms[_lib.TIME_SYRK_SUM],
                           "avg_launch_us": 1e3 * ms[_lib.TIME_SYRK_SUM] / max(1, int(ms[_lib.TIME_SYRK_N])),
                           "achieved_tflops": ms[_lib.TIME_SYRK_FLOP] / (ms[_lib.TIME_SYRK_SUM] * 1e-3) / 1e12,
-                          "lauum_ms": ms[_lib.TIME_LAUUM], "source_hash": source_hash()}))
+                          "lauum_ms": ms[_lib.TIME_LAUUM], "lauum_ms_per_step": lauum_ms,
+                          "lauum_flops": S * float(Nn) ** 3 / 3.0, "lauum_clock": clk, "sites": S, "N": Nn,
+                          "stages_ms": {"gram": ms[_lib.TIME_GRAM], "potrf_wall": ms[_lib.TIME_POTRF], "trtri": ms[_lib.TIME_TRTRI],
+                                        "lauum": ms[_lib.TIME_LAUUM], "solve": ms[_lib.TIME_SOLVE], "grad": ms[_lib.TIME_GRAD]},
+                          "source_hash": source_hash()}))
         return
     torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -771,8 +851,15 @@ def main():
         torch.cuda.synchronize()
         single_ms = (time.perf_counter() - t1) / ksingle * 1e3
 
+    N = bplan.N
+    train = None
+    if args.train > 0:  # every rank takes part (fit_many_distributed); the step metric's plans are released first
+        del bplan, plan
+        bplan = plan = None
+        torch.cuda.empty_cache()
+        train = train_many(model, n, world * S, args.train, barrier=barrier, distributed=True)
+        train["ranks"] = world
     if rank == 0:
-        N = bplan.N
         dom = rep["dominant"]
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, gfx950 half-count correction applied: scripts/pmc_summary.py); only valid
@@ -836,6 +923,8 @@ def main():
                             "note": "one site alone on one GPU, steps strictly sequential (a single fit loop)"},
             "roofline": roofline,
         }
+        if train is not None:
+            result["train"] = train
         default_run = (world == 1 and (model, n, d, args.dtype) == ("loadest", 8192, 3, "f64"))
         del bplan, plan
         torch.cuda.empty_cache()

@@ -312,6 +312,9 @@ int dgp_plan_set_option(dgp_plan* p, int key, int64_t value) {
     case DGP_OPT_CHAIN_YIELD:
       p->tune.chain_yield = value ? 1 : 0;
       return 0;
+    case DGP_OPT_FUSED_GRAD:
+      p->tune.fused_grad = value ? 1 : 0;
+      return 0;
     case DGP_OPT_REFINE:
       if (p->dtype != DGP_F32 && value) return fail(DGP_E_ARG, "dgp_plan_set_option: refinement applies to float32 plans");
       p->refine = value ? 1 : 0;
@@ -330,6 +333,7 @@ int dgp_plan_get_option(const dgp_plan* p, int key, int64_t* value) {
     case DGP_OPT_SYRK_ORDER: *value = p->tune.syrk_super; return 0;
     case DGP_OPT_LAUUM_ORDER: *value = p->tune.lauum_super; return 0;
     case DGP_OPT_CHAIN_YIELD: *value = p->tune.chain_yield; return 0;
+    case DGP_OPT_FUSED_GRAD: *value = p->tune.fused_grad; return 0;
     default: return fail(DGP_E_ARG, "dgp_plan_get_option: unknown option");
   }
 }
@@ -678,6 +682,27 @@ static int run_grad(dgp_plan* p, const double* theta, void* dtheta, hipStream_t 
                       (T*)p->gpart, (T*)dtheta, s, batch_of<T>(p), DGP_OUT_LEN, p->pre, p->pre_ready != 0);
 }
 
+// DGP_SOLVE_OVERLAP: 0 = solves in front of lauum on the caller's stream (the order until round 4); 1 (default) = on the bulk
+// stream (lowest priority: the trmv workgroups fill whatever slots lauum's grid leaves); 2 = on the rest stream (highest
+// priority).  Needs the plan's event pool (lookahead >= 1).  Measured on one box in alternating processes
+// (scripts/env_ab.py, wall ms per step, 0 / 1 / 2): 32 x n = 8192 274.3 / 273.8 / 274.4 (lauum itself 81.0 -> 83.3 with the
+// solves beside it: its three workgroups per CU leave a trmv wave no registers, so the solves take slots, not idle
+// resources), 64 x n = 4096 80.56 / 79.30 / 79.59 (-1.6 %), one site n = 8192 11.85 / 11.84 / 11.81; bitwise the same results.
+template <typename T>
+static int solve_overlap_mode(dgp_plan* p, hipStream_t s, hipStream_t* out) {
+  static const int mode = getenv("DGP_SOLVE_OVERLAP") ? atoi(getenv("DGP_SOLVE_OVERLAP")) : 1;
+  if (mode <= 0 || !p->lookahead || !p->ev || p->nev < 2) return 0;
+  if (sizeof(T) == 4 && p->refine) return 0;
+  if (mode == 1 && p->s2) {
+    *out = p->s2;
+    return 1;
+  }
+  StreamSet* st = stream_set(s);
+  if (!st || make_stream(&st->rest, true)) return 0;
+  *out = st->rest;
+  return 2;
+}
+
 template <typename T>
 static int fit_step(dgp_plan* p, const double* theta, const void* r, const void* noise, void* out, void* dr,
                     void* dnoise, int with_grad, hipStream_t s) {
@@ -741,16 +766,46 @@ static int fit_step(dgp_plan* p, const double* theta, const void* r, const void*
     if ((rc = run_trtri<T>(p, s))) return rc;
     tick(p, TS_TRTRI, 1, s);
   }
-  tick(p, TS_SOLVE, 0, s);
-  if ((rc = run_solve<T>(p, r, s))) return rc;
-  if ((rc = run_refine<T>(p, theta, r, noise, s))) return rc;
-  tick(p, TS_SOLVE, 1, s);
+  // The two triangular solves (HBM-bound: z = T r, alpha = T^T z read T twice) need T and r only, and K^^-1 = T^T T
+  // (MFMA-bound) needs T only: with a second stream at hand the solves run BESIDE lauum instead of in front of it and join
+  // before the gradient contraction, which needs both.  fp32 plans with the refinement keep the order: its scratch is S.
+  // (the FUSED kernel -- K^^-1 with the gradient contraction in its epilogue, dgp_fused.hip -- needs alpha before it
+  // starts: the solves then stay in front of it on the caller's stream)
+  const bool fused = with_grad && p->tune.fused_grad && lauum_grad_applies(p->model, p->N, bt);
+  hipStream_t ss = s;
+  const int ov = (with_grad && !fused) ? solve_overlap_mode<T>(p, s, &ss) : 0;
+  if (ov) {
+    hipEventRecord(p->ev[0], s);
+    hipStreamWaitEvent(ss, p->ev[0], 0);
+  }
+  tick(p, TS_SOLVE, 0, ss);
+  if ((rc = run_solve<T>(p, r, ss))) return rc;
+  if ((rc = run_refine<T>(p, theta, r, noise, ss))) return rc;
+  tick(p, TS_SOLVE, 1, ss);
+  if (ov) hipEventRecord(p->ev[1], ss);
   p->timed_valid = 0;
   p->have_inverse = 0;
-  if (with_grad) {
+  if (!with_grad && ov) hipStreamWaitEvent(s, p->ev[1], 0);
+  if (fused) {
+    // TIME_LAUUM then covers the fused launch (N^3/3 flop on MFMA + the contraction's vector work beside it), TIME_GRAD the
+    // second reduction stage alone
+    tick(p, TS_LAUUM, 0, s);
+    void* staging = (p->pre && !p->pre_ready) ? p->ring.acquire(pre_scratch_bytes(p->B)) : nullptr;
+    rc = lauum_grad<T>(p->model, p->d, (const T*)p->Tm, p->N, (T*)p->S, (const T*)p->Xt, (int)p->n, theta, (const T*)p->alpha,
+                       (T*)p->gpart, (T*)out + DGP_OUT_DTHETA, s, bt, DGP_OUT_LEN, p->pre, p->pre_ready != 0, staging);
+    if (staging) p->ring.commit(s);
+    if (rc) return rc;
+    p->pre_ready = 1;
+    tick(p, TS_LAUUM, 1, s);
+    tick(p, TS_GRAD, 0, s);
+    tick(p, TS_GRAD, 1, s);
+    p->timed_valid = p->timing && p->tev;
+    p->have_inverse = 1;
+  } else if (with_grad) {
     tick(p, TS_LAUUM, 0, s);
     if ((rc = run_lauum<T>(p, s))) return rc;
     tick(p, TS_LAUUM, 1, s);
+    if (ov) hipStreamWaitEvent(s, p->ev[1], 0);
     tick(p, TS_GRAD, 0, s);
     if ((rc = run_grad<T>(p, theta, (T*)out + DGP_OUT_DTHETA, s))) return rc;
     tick(p, TS_GRAD, 1, s);

@@ -180,6 +180,11 @@ const Tuning& default_tuning() {
     v.syrk_super = getenv("DGP_SYRK_ORDER") ? atoi(getenv("DGP_SYRK_ORDER")) : 0;
     v.lauum_super = getenv("DGP_LAUUM_ORDER") ? atoi(getenv("DGP_LAUUM_ORDER")) : 0;
     v.chain_yield = getenv("DGP_CHAIN_YIELD") ? atoi(getenv("DGP_CHAIN_YIELD")) : 1;
+    // off: measured on one box in alternating processes (scripts/env_ab.py, wall ms per step, 0 / 1): 32 x n = 8192 273.9 /
+    // 275.5, 64 x n = 4096 79.5 / 80.1, one site n = 8192 11.86 / 11.86 -- the contraction's fp64 vector work costs the fused
+    // launch what it cost alone (lauum 81.0 -> 85.9 ms for 5.8 ms of gram_grad): it does not hide under the other
+    // workgroups' MFMAs
+    v.fused_grad = getenv("DGP_FUSED_GRAD") ? atoi(getenv("DGP_FUSED_GRAD")) : 0;
     if (v.syrk_slots < 1) v.syrk_slots = 1;
     return v;
   }();
@@ -572,7 +577,10 @@ __global__ __launch_bounds__(256) void crit_kernel(T* __restrict__ A, long ld, i
 }
 __global__ void chain_signal_kernel(int* word, int value, int* also_zero = nullptr) {
   if (threadIdx.x == 0) {
-    if (also_zero) __hip_atomic_store(also_zero, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (also_zero) {  // = the plan's info block: a stale status (info[0]) and a stale abort word would make the waiters leave
+      __hip_atomic_store(also_zero, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(also_zero + CHAIN_ABORT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -701,7 +709,7 @@ int potrf_split(T* A, long N, T* Tinv, T* logdet, int* info, T* snap, hipStream_
     // The rest stream's first trsm polls info[CHAIN_DIAG_DONE], which still holds the LAST step's final value until this
     // factorisation's first diagonal-block kernel resets the status words: clear it here, on s, and let c2 start behind
     // that (one event per factorisation; without it trsm(0) could run ahead of diag(0) on stale data)
-    chain_signal_kernel<<<1, 64, 0, s>>>(info + CHAIN_DIAG_DONE, 0, info);  // (and info[0]: a stale time-out code would make the waiters leave)
+    chain_signal_kernel<<<1, 64, 0, s>>>(info + CHAIN_DIAG_DONE, 0, info);  // (and info[0] / info[CHAIN_ABORT]: a stale time-out would make the waiters leave)
     hipEventRecord(ED[0], s);
     hipStreamWaitEvent(c2, ED[0], 0);
     snap_copy_kernel<T><<<8, 256, 0, s>>>(A, N, 1, 0, snap + (long)NB * NB);  // rows of block 1 of panel 0, before their trsm

@@ -25,6 +25,7 @@ struct Tuning {
   int syrk_super;         // tile order of the bulk update: 0 = rows of the trailing matrix, S > 0 = S x S supertiles (experiment)
   int lauum_super;        // tile order of K^^-1 = L^-T L^-1: 0 = rows, S > 0 = S x S supertiles dealt round-robin over the XCDs
   int chain_yield;        // single-site plans: bulk-update waves leave their CU to the diagonal-block kernel while it runs there (1)
+  int fused_grad;         // the gradient contraction runs in the epilogue of K^^-1's 128 x 128 tiles (dgp_fused.hip) when it applies (1)
 };
 const Tuning& default_tuning();
 struct Batch {
@@ -70,6 +71,11 @@ int gram_residual(int model, int d, const TS* Xt, long N, int n, const double* t
                   void* pre_scratch, void* pre_staging);
 size_t gram_residual_scratch_bytes(long N);  // part + rho64 + rho32 + delta, per site
 long gram_grad_partials(long N);
+// ---- dgp_fused.hip: K^^-1 = L^-T L^-1 with the gradient contraction in the epilogue of every 128 x 128 tile
+bool lauum_grad_applies(int model, long N, const Batch& bt);
+template <typename T>
+int lauum_grad(int model, int d, const T* Tm, long N, T* S, const T* Xt, int n, const double* theta, const T* alpha, T* partials,
+               T* dtheta, hipStream_t s, Batch bt, long dtheta_stride, void* pre_scratch, bool pre_ready, void* pre_staging);
 template <typename T>
 int mean_vjp_grad(int model, int d, const T* Xt, long N, int n, const T* Xst, long Mp, int m, const double* theta,
                   const T* alpha, const T* beta, const T* wts, T* partials, T* dtheta, hipStream_t s, Batch bt = Batch(),

@@ -31,7 +31,7 @@ namespace dgp {
 // polynomial (truncation r^6 / 720 < 3.5e-17 relative).  13 VALU + 1 LDS instruction against 21 VALU for the table-free
 // version (same range reduction by ln2, degree-13 polynomial) this replaces.  Every kernel that evaluates a covariance
 // in double calls exp_table_init() before the barrier that precedes its first pair().
-__constant__ double dgp_exp_tab_c[64] = {
+static __constant__ double dgp_exp_tab_c[64] = {
     1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
     1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
     1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
@@ -48,7 +48,7 @@ __constant__ double dgp_exp_tab_c[64] = {
     1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
     1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
     1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
-__shared__ double dgp_exp_tab[64];
+static __shared__ double dgp_exp_tab[64];
 template <typename T>
 __device__ __forceinline__ void exp_table_init() {
   if (sizeof(T) == 8 && threadIdx.x < 64) dgp_exp_tab[threadIdx.x] = dgp_exp_tab_c[threadIdx.x];

@@ -149,6 +149,12 @@ int dgp_plan_set_lookahead(dgp_plan* plan, int level);
  * block kernel is one workgroup of dependent latencies on the critical path and runs 3-5 times slower beside them.  A
  * scheduling hint: results are bitwise the same with 0. */
 #define DGP_OPT_CHAIN_YIELD 6
+/* default 0 (a measured alternative, not faster: csrc/dgp_fused.hip): 1 = when K^^-1 = L^-T L^-1 runs in 128 x 128 tiles (see
+ * DGP_OPT_LAUUM64_MAX_TILES) and the model is one of the two fused covariance functions, every tile contracts itself with
+ * dK/dtheta right after it is stored (one launch instead of lauum + gram_grad; K^^-1 is never re-read from HBM).  Same sums in
+ * a different order: the gradients agree to rounding (1e-11 relative in fp64), everything else is bitwise the same.  The
+ * backward pass of engines/gpytorch.py:384. */
+#define DGP_OPT_FUSED_GRAD 7
 int dgp_plan_set_option(dgp_plan* plan, int key, int64_t value);
 int dgp_plan_get_option(const dgp_plan* plan, int key, int64_t* value_out);
 int dgp_plan_buffer(const dgp_plan* plan, int which, void** dev_ptr, int64_t* ld);

@@ -8,6 +8,10 @@ def nm(r): return r["Kernel_Name"].split("(")[0].replace("void dgp::", "").repla
 # last fit = after the last gram_sym
 idx = max(i for i, r in enumerate(rows) if "gram_sym" in r["Kernel_Name"])
 last = rows[idx:]
+# ... up to the step's own finish_kernel: what follows (the clock probe's loop of lauum launches in --roofline-only runs) is not the step
+fin = [i for i, r in enumerate(last) if "finish_kernel" in r["Kernel_Name"] and "symv" not in r["Kernel_Name"] and "refine" not in r["Kernel_Name"] and "predict" not in r["Kernel_Name"]]
+if fin:
+    last = last[: fin[0] + 1]
 t0 = int(last[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in last)
 print(f"last fit wall {(t1-t0)/1e3:.1f} us, {len(last)} kernels")
 agg = {}

@@ -47,7 +47,8 @@ def test_a_foreign_world_size_is_refused():
 def test_plain_gpus_2_starts_two_ranks_and_prints_one_line(gpu_device):
     """The plain command on the one-GPU box: two ranks share the card over gloo (RCCL refuses two ranks on one device)."""
     S = 3
-    cmd = [sys.executable, BENCH, "--gpus", "2", "--size", "1024", "--steps", "2", "--warmup", "1", "--sites-per-gpu", str(S)]
+    cmd = [sys.executable, BENCH, "--gpus", "2", "--size", "1024", "--steps", "2", "--warmup", "1", "--sites-per-gpu", str(S),
+           "--train", "4"]
     run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
                          env=_clean_env(DGP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert run.returncode == 0, run.stderr[-3000:]
@@ -62,6 +63,10 @@ def test_plain_gpus_2_starts_two_ranks_and_prints_one_line(gpu_device):
     # the headline configuration's own parity record travels with the line (site 0 of the batch against a single-site plan)
     par = rec["config"]["parity"]
     assert par["ok"] is True and par["nll_rel"] <= 1e-11
+    # --train K: the 2 S sites trained for K iterations across the two ranks (fit_many_distributed), next to the step metric
+    tr = rec["train"]
+    assert tr["sites"] == 2 * S and tr["iterations"] == 4 and tr["ranks"] == 2 and tr["ok"] is True
+    assert tr["site_iterations_per_s"] > 0 and abs(tr["site_iterations_per_s"] * tr["seconds"] - 2 * S * 4) < 1e-6
 
 
 @pytest.mark.gpu

@@ -164,3 +164,52 @@ def test_chain_yield_is_a_scheduling_hint_only(dtype, gpu_device):
         assert rows[0][0][_lib.OUT_INFO] == 0 and bool(torch.isfinite(rows[0][0][:15]).all())
         for o, a, dn in rows[1:]:
             assert torch.equal(o, rows[0][0]) and torch.equal(a, rows[0][1]) and torch.equal(dn, rows[0][2])
+
+
+@pytest.mark.parametrize("model,d,n,B", [("loadest", 3, 1300, 1), ("rating", 2, 1000, 1), ("loadest", 4, 900, 3), ("loadest", 3, 1100, 10)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_fused_gradient_epilogue_against_the_two_launch_path(model, d, n, B, dtype, gpu_device):
+    """`DGP_OPT_FUSED_GRAD` (round 5, csrc/dgp_fused.hip): every 128 x 128 tile of K^^-1 = L^-T L^-1 contracts itself with
+    dK/dtheta right after it is stored, instead of a second kernel streaming K^^-1 again.  Against the two-launch path
+    (lauum_kernel + gram_grad_kernel) on the same plan: K^^-1, the NLL, alpha and dnoise are BITWISE the same (the k-loop and
+    the store are lauum_kernel's), the hyperparameter gradient is the same sum of the same products in a different order
+    (128- instead of 64-tiles in the first stage).  Error model for the bound: ~n^2 / 2 = 5e5 terms whose sum cancels to
+    ~1e-2 of their absolute sum, each product exact to eps: relative difference <= 100 eps sqrt(n^2 / 2) ~ 1e-11 (fp64),
+    6e-3 worst case in fp32 where every pair evaluation itself carries ~1e-6 (asserted at 2e-4, like the oracle bound / 50).
+    Site 0's fused gradient is also held against the dense oracle at the usual 1e-8 (fp32: 1e-2).  B = 10: hyperparameters
+    through device scratch.  Reference: the backward of engines/gpytorch.py:384."""
+    from discontinuum_amd import _lib
+
+    dev = gpu_device
+    cases = [make_case(model, d, n, seed=60 + b, perturb=0.25) for b in range(B)]
+    X = torch.stack([c[0] for c in cases]).to(dev, dtype).contiguous()
+    r = torch.stack([c[1] for c in cases]).to(dev, dtype).contiguous()
+    noise = torch.stack([c[2] for c in cases]).to(dev, dtype).contiguous()
+    theta = torch.stack([c[3] for c in cases])
+    P = theta.shape[1]
+    if B == 1:
+        X, r, noise, theta = X[0].contiguous(), r[0].contiguous(), noise[0].contiguous(), theta[0]
+    p = forced_plan(model, d, n, X if B == 1 else None, dtype, dev, lookahead=1 if B > 1 else 2, batch=B)
+    p.set_inputs(X)
+    rows = {}
+    for fused in (1, 0):
+        p.set_option(_lib.OPT_FUSED_GRAD, fused)
+        assert p.get_option(_lib.OPT_FUSED_GRAD) == fused
+        out, alpha, dnoise = p.fit_step(theta, r, noise)
+        S = [torch.tril(p.buffer(_lib.BUF_S, site=b))[:n, :n].clone() for b in (0, B - 1)]
+        rows[fused] = (out.reshape(B, -1).cpu().double(), alpha.cpu(), dnoise.cpu(), S)
+        assert bool((rows[fused][0][:, _lib.OUT_INFO] == 0).all())
+    (of, af, nf, Sf), (o2, a2, n2, S2) = rows[1], rows[0]
+    assert torch.equal(af, a2) and torch.equal(nf, n2) and all(torch.equal(x, y) for x, y in zip(Sf, S2))
+    keep = [k for k in range(_lib.OUT_LEN) if not _lib.OUT_DTHETA <= k < _lib.OUT_DTHETA + P]
+    assert torch.equal(of[:, keep], o2[:, keep])
+    g = slice(_lib.OUT_DTHETA, _lib.OUT_DTHETA + P)
+    err = ((of[:, g] - o2[:, g]).abs().max(dim=1).values / o2[:, g].abs().max(dim=1).values).max().item()
+    assert err <= (1e-11 if dtype == torch.float64 else 2e-4), err
+    _, g_ref, _, _ = orc.nll_data_and_grads(model, *cases[0][:3], cases[0][3])
+    e_g = ((of[0, g] - g_ref).abs().max() / g_ref.abs().max()).item()
+    assert e_g < (1e-8 if dtype == torch.float64 else 1e-2), e_g
+    # and repeatable bit for bit
+    p.set_option(_lib.OPT_FUSED_GRAD, 1)
+    again = p.fit_step(theta, r, noise)[0].reshape(B, -1).cpu().double()
+    assert torch.equal(again, of)
