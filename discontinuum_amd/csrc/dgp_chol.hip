@@ -122,7 +122,8 @@ struct YieldHook {
     yield_refresh(word, (unsigned)(size_t)(dgp_lds_ptr)copy);
   }
 };
-template <typename T, int BM, int BN, bool POLITE = false>
+// STREAM: the tile of C with non-temporal loads / stores (dgp_gemm.h::trailing_begin) -- the bulk update
+template <typename T, int BM, int BN, bool POLITE = false, bool STREAM = false>
 __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int nk, long row0, long col0,
                                           T* __restrict__ smem, const unsigned* yield_word = nullptr, unsigned me = 0,
                                           const unsigned* yield_copy = nullptr) {
@@ -131,15 +132,15 @@ __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
   typename G::acc_t keep[G::MI][G::NI];
-  trailing_begin<T, G, K::DMA>(acc, keep, C, ld);
+  trailing_begin<T, G, K::DMA, STREAM>(acc, keep, C, ld);
   if constexpr (POLITE)
     K::run_hooked(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc, YieldHook{yield_word, me, yield_copy});
   else
     K::run(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc);
-  trailing_end<T, G, K::DMA>(acc, keep, C, ld);
+  trailing_end<T, G, K::DMA, STREAM>(acc, keep, C, ld);
 }
 
-template <typename T, bool POLITE = false>
+template <typename T, bool POLITE = false, bool STREAM = false>
 __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg, int nfull,
                                                                                    int split, long bs, int nt = 0, int super = 0,
                                                                                    const unsigned* yield_word = nullptr) {
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kern
     // all tiles cost the same: remap freely -- consecutive logical tiles on one XCD; `super` picks the logical order
     if (super > 0) super_decode(xcd_remap(b, nfull), nt, super, bi, bj);
     else tri_decode(xcd_remap(b, nfull), bi, bj);
-    syrk_tile<T, 128, 128, POLITE>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem, yield_word, POLITE ? cu_code() : 0u,
+    syrk_tile<T, 128, 128, POLITE, STREAM>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem, yield_word, POLITE ? cu_code() : 0u,
                                    yield_copy + (POLITE ? 64 * __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0));
     return;
   }
@@ -162,10 +163,10 @@ __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kern
   const long row0 = (long)(bi + jbeg) * NB, col0 = (long)(bj + jbeg) * NB;
   const int part = sub % split;
   if (split == 2) {
-    syrk_tile<T, 64, 128>(A, ld, k, nk, row0 + 64 * part, col0, smem);
+    syrk_tile<T, 64, 128, false, STREAM>(A, ld, k, nk, row0 + 64 * part, col0, smem);
   } else {
     if (bi == bj && part == 1) return;  // strictly upper quadrant of a diagonal tile
-    syrk_tile<T, 64, 64>(A, ld, k, nk, row0 + 64 * (part >> 1), col0 + 64 * (part & 1), smem);
+    syrk_tile<T, 64, 64, false, STREAM>(A, ld, k, nk, row0 + 64 * (part >> 1), col0 + 64 * (part & 1), smem);
   }
 }
 
@@ -238,14 +239,14 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, lon
 
 // the same columns in 128 x 128 tiles of the direct-to-LDS core, for batched plans: there the group's column update is
 // thousands of tiles and not latency-critical (the sites fill each other's gaps); bitwise the same sums
-template <typename T>
+template <typename T, bool STREAM = false>
 __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_col128_kernel(T* __restrict__ A, long ld, int k, int nk, int jcol,
                                                                                           int nbk, int ncol, long bs) {
   __shared__ T smem[TileCore<T, true, true>::SMEM_ELEMS];
   A += (long)((int)blockIdx.z / ncol) * bs;
   const int jc = jcol + (int)blockIdx.z % ncol;
   if ((int)blockIdx.x >= nbk - jc) return;  // the later columns are shorter
-  syrk_tile<T, 128, 128>(A, ld, k, nk, (long)(jc + (int)blockIdx.x) * NB, (long)jc * NB, smem);
+  syrk_tile<T, 128, 128, false, STREAM>(A, ld, k, nk, (long)(jc + (int)blockIdx.x) * NB, (long)jc * NB, smem);
 }
 
 // launch the LDS-resident diagonal-block kernel (needs > 64 KB of dynamic LDS: opt in once per instantiation).
@@ -294,11 +295,20 @@ static void launch_bulk(T* A, long N, int k, int nk, int jbeg, const SyrkShape& 
   static const int pad_env = getenv("DGP_BULK_LDS_PAD") ? std::min(16384, std::max(0, atoi(getenv("DGP_BULK_LDS_PAD")))) : 14336;
   // (batched plans: 64 x 4096 797 -> 789 fits/s, 32 x 8192 115.6 -> 115.0, 128 x 2048 no change -- their chain kernels are wide enough)
   const size_t pad = (bt.B == 1 && nbk >= 40 && nbk <= 160) ? (size_t)pad_env : 0;
-  if (yields(bt))
-    syrk_kernel<T, true><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super,
-                                              reinterpret_cast<const unsigned*>(info + CHAIN_YIELD));
-  else
-    syrk_kernel<T, false><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
+  // DGP_BULK_STREAM=1: the tiles of C through non-temporal loads / stores (dgp_gemm.h: STREAM).  A measurement knob, default
+  // off: the tile ALONE gains 7 % at K = 512 (65.3 -> 69.8 TFLOP/s, scripts/syrk_persist.hip), and in situ the bulk launches'
+  // sum drops 79.2 -> 75.7 ms at 32 x n = 8192 -- but the step does not move (275.6 / 275.9 ms; n = 32768 fp64 515.9 -> 513.5;
+  // fp32, whose tiles read C in the epilogue, loses: n = 16384 38.18 -> 38.70 ms): beside the chain's kernels the stalled
+  // cycles of a bulk workgroup were not idle cycles of the GPU (scripts/env_ab.py, one box, alternating processes)
+  static const bool stream = getenv("DGP_BULK_STREAM") ? atoi(getenv("DGP_BULK_STREAM")) != 0 : false;
+  const unsigned* yw = reinterpret_cast<const unsigned*>(info + CHAIN_YIELD);
+  if (yields(bt)) {
+    if (stream) syrk_kernel<T, true, true><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, yw);
+    else syrk_kernel<T, true, false><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, yw);
+  } else {
+    if (stream) syrk_kernel<T, false, true><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
+    else syrk_kernel<T, false, false><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
+  }
 }
 template <typename TS, typename TC>
 static void launch_diag_as(TS* A, long N, long k0, TS* Tinv, TS* logdet, int* info, hipStream_t s, Batch bt, bool init,
@@ -396,7 +406,12 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
       if (q >= 2) hipStreamWaitEvent(s, U[q - 2], 0);  // bulk(q-2) exists whenever chain(q) does
       if (q >= 1) {
         static const int col128 = getenv("DGP_COL128") ? atoi(getenv("DGP_COL128")) : 4;  // batch size from which the group's columns use 128-tiles
-        if (bt.B >= col128) syrk_col128_kernel<T><<<dim3(nbk - k0, 1, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
+        if (bt.B >= col128) {
+          // DGP_COL_STREAM=1: the group's look-ahead column update with non-temporal accesses too (A/B; default plain)
+          static const bool cstream = getenv("DGP_COL_STREAM") ? atoi(getenv("DGP_COL_STREAM")) != 0 : false;
+          if (cstream) syrk_col128_kernel<T, true><<<dim3(nbk - k0, 1, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
+          else syrk_col128_kernel<T, false><<<dim3(nbk - k0, 1, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
+        }
         else syrk_col_kernel<T><<<dim3(2 * (nbk - k0), 2, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
       }
       if (q >= 1 && k0 + G < nbk) {  // bulk(q-1): columns >= G(q+1) exist

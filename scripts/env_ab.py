@@ -38,7 +38,7 @@ def child(n, S, steps, dtype):
     st = plan.get_timing()
     nll = float(out.reshape(S, -1)[0, _lib.OUT_NLL])
     print(f"RESULT {ms:.4f} {st[_lib.TIME_POTRF]:.3f} {st[_lib.TIME_TRTRI]:.3f} {st[_lib.TIME_LAUUM]:.3f} {st[_lib.TIME_SOLVE]:.3f} "
-          f"{st[_lib.TIME_GRAD]:.3f} {st[_lib.TIME_GRAM]:.3f} {nll!r}", flush=True)
+          f"{st[_lib.TIME_GRAD]:.3f} {st[_lib.TIME_GRAM]:.3f} {nll!r} {st[_lib.TIME_SYRK_SUM]:.3f} {int(st[_lib.TIME_SYRK_N])}", flush=True)
 
 
 def main():
@@ -71,7 +71,7 @@ def main():
             ms = [float(r[0]) for r in rows[v]]
             last = rows[v][-1]
             print(f"{var}={v:>3s}  n={n} S={S} {a.dtype}: wall ms/step min {min(ms):8.3f}  all {[round(x, 3) for x in ms]}  "
-                  f"stages(last) potrf {last[1]} trtri {last[2]} lauum {last[3]} solve {last[4]} grad {last[5]} gram {last[6]}  nll {last[7]}",
+                  f"stages(last) potrf {last[1]} trtri {last[2]} lauum {last[3]} solve {last[4]} grad {last[5]} gram {last[6]} bulk-sum {last[8]} ({last[9]} launches)  nll {last[7]}",
                   flush=True)
 
 
