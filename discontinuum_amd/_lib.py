@@ -17,7 +17,7 @@ MODEL_LOADEST, MODEL_RATING = 0, 1
 OUT_NLL, OUT_QUAD, OUT_LOGDET, OUT_INFO, OUT_DTHETA, OUT_SUM_DR, OUT_DR_W0, OUT_SUM_DNOISE, OUT_LEN = 0, 1, 2, 3, 4, 28, 29, 31, 32
 BUF_XT, BUF_A, BUF_T, BUF_S, BUF_Z, BUF_ALPHA = range(6)
 BUF_SCAL = 7
-OPT_LAUUM64_MAX_TILES, OPT_SYRK_SLOTS, OPT_TRTRI_SMALL, OPT_REFINE, OPT_SYRK_ORDER, OPT_LAUUM_ORDER, OPT_CHAIN_YIELD, OPT_FUSED_GRAD = range(8)
+OPT_LAUUM64_MAX_TILES, OPT_SYRK_SLOTS, OPT_TRTRI_SMALL, OPT_REFINE, OPT_SYRK_ORDER, OPT_LAUUM_ORDER, OPT_CHAIN_YIELD, OPT_FUSED_GRAD, OPT_GROUP_GEMM = range(9)
 TIME_GRAM, TIME_POTRF, TIME_SYRK_SUM, TIME_SYRK_N, TIME_TRTRI, TIME_LAUUM, TIME_SOLVE, TIME_GRAD, TIME_SYRK_FLOP, TIME_COUNT = range(10)
 
 

@@ -315,6 +315,9 @@ int dgp_plan_set_option(dgp_plan* p, int key, int64_t value) {
     case DGP_OPT_FUSED_GRAD:
       p->tune.fused_grad = value ? 1 : 0;
       return 0;
+    case DGP_OPT_GROUP_GEMM:
+      p->tune.group_gemm = value ? 1 : 0;
+      return 0;
     case DGP_OPT_REFINE:
       if (p->dtype != DGP_F32 && value) return fail(DGP_E_ARG, "dgp_plan_set_option: refinement applies to float32 plans");
       p->refine = value ? 1 : 0;
@@ -334,6 +337,7 @@ int dgp_plan_get_option(const dgp_plan* p, int key, int64_t* value) {
     case DGP_OPT_LAUUM_ORDER: *value = p->tune.lauum_super; return 0;
     case DGP_OPT_CHAIN_YIELD: *value = p->tune.chain_yield; return 0;
     case DGP_OPT_FUSED_GRAD: *value = p->tune.fused_grad; return 0;
+    case DGP_OPT_GROUP_GEMM: *value = p->tune.group_gemm; return 0;
     default: return fail(DGP_E_ARG, "dgp_plan_get_option: unknown option");
   }
 }
@@ -608,6 +612,7 @@ static Batch batch_of(const dgp_plan* p) {
   bt.ws = (long)(p->site_bytes / sizeof(T));  // layout offsets are multiples of 256 bytes
   bt.ns = p->nsite;
   bt.tune = &p->tune;
+  bt.W = p->S;  // scratch of the factorisation's group inverse (S is free until trtri / lauum use it)
   return bt;
 }
 template <typename T>

@@ -123,11 +123,11 @@ struct YieldHook {
   }
 };
 // STREAM: the tile of C with non-temporal loads / stores (dgp_gemm.h::trailing_begin) -- the bulk update
-template <typename T, int BM, int BN, bool POLITE = false, bool STREAM = false>
+template <typename T, int BM, int BN, bool POLITE = false, bool STREAM = false, int RING = 3>
 __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int nk, long row0, long col0,
                                           T* __restrict__ smem, const unsigned* yield_word = nullptr, unsigned me = 0,
                                           const unsigned* yield_copy = nullptr) {
-  using K = TileCore<T, true, true, BM, BN, (BM == 128 && BN == 128) ? Prefetch<T>::SYRK : 1>;
+  using K = TileCore<T, true, true, BM, BN, (BM == 128 && BN == 128) ? Prefetch<T>::SYRK : 1, true, false, RING>;
   using G = typename K::G;
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
@@ -140,12 +140,20 @@ __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int
   trailing_end<T, G, K::DMA, STREAM>(acc, keep, C, ld);
 }
 
-template <typename T, bool POLITE = false, bool STREAM = false>
+// RING = 2 (experiment, DGP_BULK_RING=2 with the group panel solve): a 32 KB ring, so that a CU with three of these workgroups
+// has 64 KB of LDS free and the diagonal-block kernel (94.5 KB, one workgroup per site, the only chain kernel that must run
+// BESIDE a bulk launch) would fit as soon as ONE of them retires.  Measured: it does not change when that kernel is placed --
+// the second diagonal block of a group still waits for the bulk launch to drain (2.9 ms at 64 x n = 4096 with either ring,
+// profiles/r05_experiments_group_gemm.txt), and two bulk workgroups per CU (DGP_BULK_PAD_BATCH) do not either
+template <typename T, bool POLITE = false, bool STREAM = false, int RING = 3>
 __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg, int nfull,
                                                                                    int split, long bs, int nt = 0, int super = 0,
                                                                                    const unsigned* yield_word = nullptr) {
   A = site(A, bs);
-  __shared__ T smem[TileCore<T, true, true>::SMEM_ELEMS];
+  __shared__ T smem[TileCore<T, true, true, 128, 128, 1, true, false, RING>::SMEM_ELEMS];
+  static_assert(TileCore<T, true, true, 64, 128>::SMEM_ELEMS <= TileCore<T, true, true, 128, 128, 1, true, false, RING>::SMEM_ELEMS &&
+                    TileCore<T, true, true, 64, 64>::SMEM_ELEMS <= TileCore<T, true, true, 128, 128, 1, true, false, RING>::SMEM_ELEMS,
+                "the cut remainder's register-staged tiles must fit the ring's LDS");
   __shared__ unsigned yield_copy[POLITE ? 4 * 64 : 1];  // per wave: its copy of the yield word (YieldHook)
   const int b = (int)blockIdx.x;
   int bi, bj;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kern
     // all tiles cost the same: remap freely -- consecutive logical tiles on one XCD; `super` picks the logical order
     if (super > 0) super_decode(xcd_remap(b, nfull), nt, super, bi, bj);
     else tri_decode(xcd_remap(b, nfull), bi, bj);
-    syrk_tile<T, 128, 128, POLITE, STREAM>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem, yield_word, POLITE ? cu_code() : 0u,
+    syrk_tile<T, 128, 128, POLITE, STREAM, RING>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem, yield_word, POLITE ? cu_code() : 0u,
                                    yield_copy + (POLITE ? 64 * __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0));
     return;
   }
@@ -186,6 +194,10 @@ const Tuning& default_tuning() {
     // launch what it cost alone (lauum 81.0 -> 85.9 ms for 5.8 ms of gram_grad): it does not hide under the other
     // workgroups' MFMAs
     v.fused_grad = getenv("DGP_FUSED_GRAD") ? atoi(getenv("DGP_FUSED_GRAD")) : 0;
+    // off: built, parity-green (tests/test_gpu_stages.py with the option on) and measured neutral -- 64 x n = 4096 80.8 / 80.3 ms
+    // per step, 32 x n = 8192 280.2 / 280.1, 128 x n = 2048 26.1 / 26.0 (scripts/env_ab.py, one box): the factorisation's wall
+    // time is the SUM of its full-GPU kernels at their rates whichever way the chain is cut (EXPERIMENTS.md, round 5)
+    v.group_gemm = getenv("DGP_GROUP_GEMM") ? atoi(getenv("DGP_GROUP_GEMM")) : 0;
     if (v.syrk_slots < 1) v.syrk_slots = 1;
     return v;
   }();
@@ -302,6 +314,17 @@ static void launch_bulk(T* A, long N, int k, int nk, int jbeg, const SyrkShape& 
   // cycles of a bulk workgroup were not idle cycles of the GPU (scripts/env_ab.py, one box, alternating processes)
   static const bool stream = getenv("DGP_BULK_STREAM") ? atoi(getenv("DGP_BULK_STREAM")) != 0 : false;
   const unsigned* yw = reinterpret_cast<const unsigned*>(info + CHAIN_YIELD);
+  // batched plans on the group panel solve: the 32 KB ring (syrk_kernel: RING); DGP_BULK_RING=3 keeps the 48 KB one (A/B)
+  static const int ring_env = getenv("DGP_BULK_RING") ? atoi(getenv("DGP_BULK_RING")) : 3;  // (2: measured no different, below)
+  static const int pad_batch = getenv("DGP_BULK_PAD_BATCH") ? std::min(65536, std::max(0, atoi(getenv("DGP_BULK_PAD_BATCH")))) : 0;  // experiment
+  if (bt.B >= 4 && bt.tuning().group_gemm && bt.W != nullptr && ring_env == 2) {
+    syrk_kernel<T, false, false, 2><<<grid, 256, (size_t)pad_batch, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
+    return;
+  }
+  if (bt.B >= 4 && pad_batch > 0) {
+    syrk_kernel<T, false, false><<<grid, 256, (size_t)pad_batch, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
+    return;
+  }
   if (yields(bt)) {
     if (stream) syrk_kernel<T, true, true><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, yw);
     else syrk_kernel<T, true, false><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, yw);
@@ -339,6 +362,43 @@ static void launch_diag(T* A, long N, long k0, T* Tinv, T* logdet, int* info, hi
   else
     launch_diag_as<T, T>(A, N, k0, Tinv, logdet, info, s, bt, init, logdet_hi_slot(logdet), done_index, done_value);
 }
+
+// ---- the group's panel solve as ONE GEMM (round 5; batched plans) ---------------------------------------------------------
+// The group-ahead schedule below factors a group of G panels column by column over the FULL height of the matrix: per panel a
+// column update (K = 128 h), the diagonal block, a trsm (K = 128) -- 2 G - 1 launches that each sweep the group's G x (rows
+// below) tiles with a short k-range: the chain of a batch is thousands of 64-row tiles at 45-60 % of the MFMA rate, and for
+// mid-size sites (64 x n = 4096) it, not the bulk update, bounds the factorisation (potrf wall 27.7 ms, bulk launches 16.1).
+// But only the G x G-block DIAGONAL block D of the group has to be factored panel by panel.  With L_D final and T_D = L_D^-1
+// (its diagonal 128-blocks come from the diagonal-block kernel, the rest from the first log2(G) levels of the inverse's own
+// recursion, restricted to D: work the inverse stage would do anyway), the rows below are
+//     L[i, group] = A[i, group] T_D^T,        column block j:  sum over the column blocks c <= j of A[i, c] T_D[j, c]^T
+// -- the same flops (G (G + 1) / 2 tile products of K = 128 per row tile) in ONE launch of 128 x 128 tiles on the direct-to-LDS
+// core with k-ranges of 128 .. 128 G, in place (column block j is written after every product that reads it; j descends).
+// Not bitwise the panel-by-panel chain (a different association of the same sums): batched plans against single-site plans
+// agree to rounding, ~1e-13 relative in fp64 (tests/test_gpu_stages.py, test_gpu_headline_shape.py hold 1e-11).
+template <typename T>
+__global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void trsm_group_kernel(T* __restrict__ A, const T* __restrict__ Tm, long ld,
+                                                                                         int k0, int G, long bs) {
+  A = site(A, bs);
+  Tm = site(Tm, bs);
+  using K = TileCore<T, true, true, 128, 128, 1>;
+  using Gm = typename K::G;
+  __shared__ T smem[K::SMEM_ELEMS];
+  T* Arow = A + (long)(k0 + G + (int)blockIdx.x) * NB * ld + (long)k0 * NB;  // this workgroup's 128 rows of the group's columns
+  const T* TD = Tm + (long)k0 * NB * ld + (long)k0 * NB;                      // T_D, lower triangular, zeros above the diagonal
+#pragma unroll 1
+  for (int j = G - 1; j >= 0; --j) {
+    typename Gm::acc_t acc[Gm::MI][Gm::NI];
+    Gm::zero(acc);
+    K::run(Arow, ld, TD + (long)j * NB * ld, ld, (j + 1) * (NB / 16), smem, acc);  // (every wave is past its last operand read)
+    T* out = Arow + (long)j * NB;
+    K::foreach (acc, [&](int r, int c, T& v) { out[(long)r * ld + c] = v; });
+  }
+}
+// the first log2(G) levels of the inverse's recursion for the diagonal group block at block column k0 (defined behind
+// trtri_level): T_D's off-diagonal blocks into Tm, scratch in W
+template <typename T>
+static void trtri_group(const T* L, T* Tm, T* W, long N, int k0, int G, hipStream_t s, Batch bt);
 
 template <typename T>
 int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_t s, hipStream_t s2, hipEvent_t* ev,
@@ -427,12 +487,22 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
         ++ns;
         hipEventRecord(U[q - 1], s2);
       }
+      // the group's panel solve as one GEMM (trsm_group_kernel): batches from 4 sites (the chain is then wide enough to be
+      // throughput-, not latency-bound), full groups with rows below them, G a power of two (the inverse's levels)
+      const bool group_gemm = bt.tuning().group_gemm && bt.W != nullptr && bt.B >= 4 && ncol == G && k0 + G < nbk && (G & (G - 1)) == 0 &&
+                              G >= 2 && nck == 0 && carry == nullptr;
+      const int kend = group_gemm ? k0 + G : nbk;  // the panel-by-panel chain covers block rows < kend
       for (int h = 0; h < ncol; ++h) {
         const int k = k0 + h;
-        if (h >= 1) syrk_col_kernel<T><<<dim3(2 * (nbk - k), 2, Bz), 256, 0, s>>>(A, N, k0, h, k, nbk, 1, bt.ws);
+        if (h >= 1) syrk_col_kernel<T><<<dim3(2 * (kend - k), 2, Bz), 256, 0, s>>>(A, N, k0, h, k, kend, 1, bt.ws);
         launch_diag<T>(A, N, (long)k * NB, Tinv, logdet, info, s, bt, k == 0);
-        if (k + 1 < nbk) trsm_kernel<T><<<dim3(2 * (nbk - k - 1), 1, Bz), 256, 0, s>>>(A, Tinv, N, k, bt.ws);
-        checkpoint(k + 1);
+        if (k + 1 < kend) trsm_kernel<T><<<dim3(2 * (kend - k - 1), 1, Bz), 256, 0, s>>>(A, Tinv, N, k, bt.ws);
+        if (!group_gemm) checkpoint(k + 1);
+      }
+      if (group_gemm) {
+        trtri_group<T>(A, Tinv, (T*)bt.W, N, k0, G, s, bt);
+        trsm_group_kernel<T><<<dim3((unsigned)(nbk - k0 - G), 1, Bz), 256, 0, s>>>(A, Tinv, N, k0, G, bt.ws);
+        checkpoint(k0 + G);
       }
     }
     // bulk(q) exists for q <= Q-3 and chain(q+2) has waited on every one of them: s is joined
@@ -1033,6 +1103,15 @@ int trtri_advance(const T* L, long N, T* Tm, T* W, int ready, TrtriProgress* st,
   }
   if (early) st->pairs_used = nctr_pairs - el.pairs_left;
   return (int)hipGetLastError();
+}
+
+template <typename T>
+static void trtri_group(const T* L, T* Tm, T* W, long N, int k0, int G, hipStream_t s, Batch bt) {
+  for (int m = 1; m < G; m *= 2) {  // level with half-size m: the groups of 2 m blocks inside [k0, k0 + G)
+    const int g0 = k0 / (2 * m), g1 = (k0 + G) / (2 * m);
+    trtri_level<T, 0>(L, Tm, W, N, N, m, g0, g1, nullptr, s, bt);
+    trtri_level<T, 1>(L, Tm, W, N, N, m, g0, g1, nullptr, s, bt);
+  }
 }
 
 template <typename T>

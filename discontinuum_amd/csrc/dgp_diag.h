@@ -321,9 +321,13 @@ __global__ __launch_bounds__(256) void potrf_diag_fast_kernel(TS* __restrict__ A
     for (int bj = bi; bj < DGP_DNB; ++bj)
       Xblk[(long)(16 * bi + ti) * ld + 16 * bj + tj] = bj == bi ? (TS)sXd[bi * DGP_DBLK + ti * DGP_DS + tj] : TS(0);
   DGP_DIAG_STAMP(6)
-  // ---- log-determinant and first bad pivot (fixed-order tree: reproducible)
-  __shared__ T red[128];
-  __shared__ int bad;
+  // ---- log-determinant and first bad pivot (fixed-order tree: reproducible).  The scratch lives in the (now dead) sub-block
+  // area: with NO static LDS the kernel's footprint is 94.5 KB = 76 allocation units of 1280 B, which is exactly what a CU
+  // has free once ONE of three 32 KB-ring bulk workgroups retires (dgp_chol.hip: syrk_kernel RING = 2); with the 1040 bytes
+  // these two used to take statically it was one unit more
+  __syncthreads();  // every wave is through with sL / sXd
+  T* red = sL;
+  int& bad = *reinterpret_cast<int*>(sL + 128);
   if (t == 0) bad = 128;
   __syncthreads();
   if (t < 128) {

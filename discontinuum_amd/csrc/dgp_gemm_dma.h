@@ -323,12 +323,14 @@ struct DmaGemm {
 // OCC is the kernel's __launch_bounds__ occupancy, SMEM_ELEMS its LDS array.
 // IL (direct-to-LDS core only): the 16-row / 16-column groups of the tile are dealt alternately to the wave rows / columns,
 // which balances zero-work skipping (TriSpec); a kernel that sets it must address its accumulators through K::foreach.
-template <typename T, bool A_KC, bool B_KC, int BM = 128, int BN = 128, int PF = 1, bool ALLOW_DMA = true, bool IL_ = false>
+// RING (direct-to-LDS core only): chunks in the operand ring, 3 (48 KB per workgroup) or 2 (32 KB: 1-2 % slower alone, but three
+// such workgroups leave 64 KB of a CU's LDS free -- one retirement away from the 94.5 KB of the diagonal-block kernel).
+template <typename T, bool A_KC, bool B_KC, int BM = 128, int BN = 128, int PF = 1, bool ALLOW_DMA = true, bool IL_ = false, int RING = 3>
 struct TileCore {
   using G = TileGemm<T, A_KC, B_KC, BM, BN>;
   static constexpr bool DMA = ALLOW_DMA && BM == 128 && BN == 128;
   static constexpr bool IL = IL_ && DMA;
-  using D = DmaGemm<T, A_KC, B_KC, 3, IL>;
+  using D = DmaGemm<T, A_KC, B_KC, RING, IL>;
   using acc_t = typename G::acc_t;  // (the members trailing_begin / trailing_end need of a tile map: dgp_gemm.h)
   static constexpr int MI = G::MI, NI = G::NI;
   static __device__ __forceinline__ void zero(acc_t (&acc)[MI][NI]) { G::zero(acc); }

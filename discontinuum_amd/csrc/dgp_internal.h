@@ -26,6 +26,8 @@ struct Tuning {
   int lauum_super;        // tile order of K^^-1 = L^-T L^-1: 0 = rows, S > 0 = S x S supertiles dealt round-robin over the XCDs
   int chain_yield;        // single-site plans: bulk-update waves leave their CU to the diagonal-block kernel while it runs there (1)
   int fused_grad;         // the gradient contraction runs in the epilogue of K^^-1's 128 x 128 tiles (dgp_fused.hip) when it applies (1)
+  int group_gemm;         // batched plans: a panel group's rows below its diagonal block are solved by ONE GEMM against the inverted
+                          // G x G-block diagonal block instead of G trsm + G - 1 column-update launches (dgp_chol.hip::potrf)
 };
 const Tuning& default_tuning();
 struct Batch {
@@ -33,6 +35,8 @@ struct Batch {
   long ws = 0;
   const int* ns = nullptr;  // device array of the sites' own sizes n_b <= n (ragged batch), or null: all n
   const Tuning* tune = nullptr;  // null: default_tuning()
+  void* W = nullptr;             // N x N scratch per site (the plan's S buffer: free during the factorisation), or null: the
+                                 // group schedule's panel solve as ONE GEMM against the inverted diagonal group block needs it
   const Tuning& tuning() const { return tune ? *tune : default_tuning(); }
 };
 int model_ntheta(int model, int d);  // number of constrained kernel hyperparameters, -1 if unsupported

@@ -155,6 +155,12 @@ int dgp_plan_set_lookahead(dgp_plan* plan, int level);
  * a different order: the gradients agree to rounding (1e-11 relative in fp64), everything else is bitwise the same.  The
  * backward pass of engines/gpytorch.py:384. */
 #define DGP_OPT_FUSED_GRAD 7
+/* batched plans of 4 or more sites (default 0: measured neutral; 1 =): the factorisation's panel GROUPS (4 panels) solve their rows below the group's
+ * diagonal block with ONE GEMM against that block's inverse -- L[i, group] = A[i, group] T_D^T -- instead of panel-by-panel trsm
+ * and column-update launches over the full height; 0 = the panel-by-panel chain (the form until round 4).  A different
+ * association of the same sums: results agree to rounding (fp64 ~1e-13).  Replaces part of what gpytorch's Cholesky does
+ * at engines/gpytorch.py:350-353. */
+#define DGP_OPT_GROUP_GEMM 8
 int dgp_plan_set_option(dgp_plan* plan, int key, int64_t value);
 int dgp_plan_get_option(const dgp_plan* plan, int key, int64_t* value_out);
 int dgp_plan_buffer(const dgp_plan* plan, int which, void** dev_ptr, int64_t* ld);

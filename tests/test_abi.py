@@ -73,6 +73,7 @@ def test_plan_options_without_a_device():
     assert lib.dgp_plan_set_option(h64, _lib.OPT_CHAIN_YIELD, 0) == 0 and get(h64, _lib.OPT_CHAIN_YIELD) == 0
     assert get(h64, _lib.OPT_FUSED_GRAD) == 0  # (default; DGP_FUSED_GRAD=1 in the environment would say 1)
     assert lib.dgp_plan_set_option(h64, _lib.OPT_FUSED_GRAD, 1) == 0 and get(h64, _lib.OPT_FUSED_GRAD) == 1
+    assert get(h64, _lib.OPT_GROUP_GEMM) == 0 and lib.dgp_plan_set_option(h64, _lib.OPT_GROUP_GEMM, 1) == 0 and get(h64, _lib.OPT_GROUP_GEMM) == 1
     assert lib.dgp_plan_set_option(h64, 99, 1) == -1 and lib.dgp_plan_get_option(h64, 99, C.byref(v)) == -1
     assert lib.dgp_plan_set_option(None, 0, 1) == -1
     assert lib.dgp_debug_clock_probe(None, 16, 0.1, None) == -1

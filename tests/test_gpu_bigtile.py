@@ -213,3 +213,55 @@ def test_fused_gradient_epilogue_against_the_two_launch_path(model, d, n, B, dty
     p.set_option(_lib.OPT_FUSED_GRAD, 1)
     again = p.fit_step(theta, r, noise)[0].reshape(B, -1).cpu().double()
     assert torch.equal(again, of)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("model,d,sizes", [("loadest", 3, [1300, 1000, 1171, 1300, 900]), ("rating", 2, [1408, 1300, 1408, 1100])])
+def test_group_panel_gemm_option(model, d, sizes, dtype, gpu_device):
+    """`DGP_OPT_GROUP_GEMM` (round 5; batched plans of >= 4 sites): a panel group's rows below its 512 x 512 diagonal block are
+    solved by ONE GEMM against that block's inverse, L[i, group] = A[i, group] T_D^T (csrc/dgp_chol.hip::trsm_group_kernel),
+    instead of panel-by-panel trsm / column-update launches.  N = 1408 = 11 block columns: two full groups take the new path,
+    the last (three panels, nothing below) the old one.  Against the dense oracle at the usual tolerances (fp64 NLL 1e-10,
+    gradients / alpha / dnoise 1e-8; fp32 NLL 1e-4 max(1, n / 1024), rest 1e-2), and in fp64 against the same plan with the
+    option off: a different association of the same sums.  Error model for that bound: the panel entries differ by
+    ~cond(L_D) eps <= 1e3 x 1.1e-16 relative, the NLL (a sum over n pivots and n residuals) by less: asserted 1e-11 on the
+    NLL and 1e-9 on gradients / alpha, a tenth of the oracle tolerances.  Measured neutral in speed (default off).
+    What it restates: the Cholesky inside the reference's `mll(output, y)`, engines/gpytorch.py:350-353."""
+    from discontinuum_amd import _lib
+
+    dev, B, n = gpu_device, len(sizes), max(sizes)
+    cases = [make_case(model, d, nb, seed=80 + b, perturb=0.2) for b, nb in enumerate(sizes)]
+    X = torch.full((B, n, d), float("nan"), dtype=torch.float64)
+    r = torch.full((B, n), float("nan"), dtype=torch.float64)
+    noise = torch.full((B, n), float("nan"), dtype=torch.float64)
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        X[b, :nb], r[b, :nb], noise[b, :nb] = c[0], c[1], c[2]
+    theta = torch.stack([c[3] for c in cases])
+    pb = forced_plan(model, d, n, None, dtype, dev, lookahead=1, batch=B)
+    pb.set_site_sizes(sizes)
+    pb.set_inputs(X.to(dev, dtype).contiguous())
+    rd, nd = r.to(dev, dtype).contiguous(), noise.to(dev, dtype).contiguous()
+    rows = {}
+    for opt in (1, 0):
+        pb.set_option(_lib.OPT_GROUP_GEMM, opt)
+        assert pb.get_option(_lib.OPT_GROUP_GEMM) == opt
+        out, dr, dnoise = pb.fit_step(theta, rd, nd)
+        rows[opt] = (out.cpu().double(), dr.cpu().double(), dnoise.cpu().double())
+    out, dr, dnoise = rows[1]
+    P = theta.shape[1]
+    g = slice(_lib.OUT_DTHETA, _lib.OUT_DTHETA + P)
+    for b, (nb, c) in enumerate(zip(sizes, cases)):
+        val, g_theta, g_r, g_noise = orc.nll_data_and_grads(model, c[0], c[1], c[2], c[3])
+        assert out[b, _lib.OUT_INFO] == 0
+        e_nll = (abs(out[b, _lib.OUT_NLL] - val) / abs(val)).item()
+        e_g = ((out[b, g] - g_theta).abs().max() / g_theta.abs().max()).item()
+        e_a = ((dr[b, :nb] - g_r).abs().max() / g_r.abs().max()).item()
+        e_n = ((dnoise[b, :nb] - g_noise).abs().max() / g_noise.abs().max()).item()
+        if dtype == torch.float64:
+            assert e_nll < 1e-10 and e_g < 1e-8 and e_a < 1e-8 and e_n < 1e-8, (b, e_nll, e_g, e_a, e_n)
+            o0, a0, _ = rows[0]
+            assert abs(out[b, 0] - o0[b, 0]) <= 1e-11 * abs(o0[b, 0])
+            assert (out[b, g] - o0[b, g]).abs().max() <= 1e-9 * o0[b, g].abs().max()
+            assert (dr[b] - a0[b]).abs().max() <= 1e-9 * a0[b].abs().max()
+        else:
+            assert e_nll < 1e-4 * max(1.0, nb / 1024) and e_g < 1e-2 and e_a < 1e-2 and e_n < 2e-2, (b, e_nll, e_g, e_a, e_n)
