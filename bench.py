@@ -866,7 +866,7 @@ def main():
         # for the shape AND the source tree those passes were taken on
         traffic, traffic_from = None, None
         shash = source_hash()
-        for cand in ("r04_pmc_hbm_n8192_f64.json", "r03_pmc_hbm_n8192_f64.json", "r02_pmc_hbm_n8192_f64.json"):
+        for cand in ("r05_pmc_hbm_n8192_f64.json", "r04_pmc_hbm_n8192_f64.json", "r03_pmc_hbm_n8192_f64.json", "r02_pmc_hbm_n8192_f64.json"):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if not os.path.exists(pmc_path) or (model, n, d, args.dtype) != ("loadest", 8192, 3, "f64"):
                 continue

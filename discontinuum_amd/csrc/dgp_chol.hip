@@ -489,8 +489,10 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
       }
       // the group's panel solve as one GEMM (trsm_group_kernel): batches from 4 sites (the chain is then wide enough to be
       // throughput-, not latency-bound), full groups with rows below them, G a power of two (the inverse's levels)
-      const bool group_gemm = bt.tuning().group_gemm && bt.W != nullptr && bt.B >= 4 && ncol == G && k0 + G < nbk && (G & (G - 1)) == 0 &&
-                              G >= 2 && nck == 0 && carry == nullptr;
+      // (one site: the groups of 4 / 8 panels that large matrices start with -- G >= 4 means N >= 12288, beyond the early inverse,
+      // which would share the scratch)
+      const bool group_gemm = bt.tuning().group_gemm && bt.W != nullptr && ncol == G && k0 + G < nbk && (G & (G - 1)) == 0 && G >= 4 &&
+                              nck == 0;
       const int kend = group_gemm ? k0 + G : nbk;  // the panel-by-panel chain covers block rows < kend
       for (int h = 0; h < ncol; ++h) {
         const int k = k0 + h;

@@ -300,3 +300,40 @@ def test_config5_single_matrix_on_one_gpu(gpu_device):
     assert e_nll < 2e-6 and e_logdet < 2e-6 and e_quad < 2e-6, (e_nll, e_quad, e_logdet)
     assert e_grad < 3e-4, e_grad
     assert e_alpha < 5e-5 and e_dnoise < 5e-5, (e_alpha, e_dnoise)
+
+
+def test_group_panel_gemm_option_on_one_large_site(gpu_device):
+    """`DGP_OPT_GROUP_GEMM` on a SINGLE site: large matrices (N >= 12288) start their factorisation in groups of four panels
+    before the split chain takes over, and with the option those groups solve their rows below the diagonal group block by
+    one GEMM (csrc/dgp_chol.hip::trsm_group_kernel), incl. the hand-over to the split chain.  n = 12288 against the same
+    plan with the option off -- a different association of the same sums; bound from the error model of
+    tests/test_gpu_bigtile.py::test_group_panel_gemm_option (NLL 1e-11, gradients / alpha 1e-9) -- and the factor identity
+    ||L L^T v - K v|| / ||K v|| < 1e-12 on the plan's own buffers."""
+    from discontinuum_amd import _lib
+    from discontinuum_amd.backend import GPPlan
+
+    dev, n, d = gpu_device, 12288, 3
+    X, y = orc.synth_loadest(n, d, seed=3)
+    Xd, yd = torch.tensor(X, device=dev), torch.tensor(y, device=dev)
+    noise = torch.full((n,), 0.01, dtype=torch.float64, device=dev)
+    theta = torch.tensor([0.9, 0.7, 1.0, 1.5, 0.6, 0.8, 1.2, 0.3, 0.9, 0.7, 1.1], dtype=torch.float64)
+    p = GPPlan("loadest", n, d, device=dev)
+    p.set_inputs(Xd)
+    p.stage_gram(theta, noise)
+    K = p.buffer(_lib.BUF_A).clone()
+    V = torch.randn(n, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(0)).to(dev)
+    KV = _sym_matvec(K, V)
+    rows = {}
+    for opt in (1, 0):
+        p.set_option(_lib.OPT_GROUP_GEMM, opt)
+        out, alpha, _ = p.fit_step(theta, yd, noise)
+        rows[opt] = (out.cpu(), alpha.cpu())
+        assert rows[opt][0][_lib.OUT_INFO] == 0
+        if opt == 1:
+            L = torch.tril(p.buffer(_lib.BUF_A))
+            assert (torch.linalg.norm(L @ (L.T @ V) - KV) / torch.linalg.norm(KV)).item() < 1e-12
+            del L
+    (o1, a1), (o0, a0) = rows[1], rows[0]
+    assert abs(o1[0] - o0[0]) <= 1e-11 * abs(o0[0])
+    assert (o1[4:15] - o0[4:15]).abs().max() <= 1e-9 * o0[4:15].abs().max()
+    assert (a1 - a0).abs().max() <= 1e-9 * a0.abs().max()
