@@ -351,9 +351,9 @@ def train_many(family, n, sites, iters, barrier=None, distributed=False):
     """The product-level many-site path (discontinuum_amd/multisite_fit.py): TRAIN `sites` independent sites of n observations for
     `iters` iterations -- one batched fit step + the vectorised host algebra + the reference's per-site optimiser semantics
     (engines/gpytorch.py:346-451) per iteration -- through `fit_many` (one process) or `fit_many_distributed` (site i on rank
-    i mod world, ONE gather of the fitted parameters at the end of the fit).  Timed twice, with `iters` and with 2 iterations:
-    the difference is the steady-state iteration, the rest is set-up (model objects, pipelines, plan creation, upload).
-    -> dict with sites x iterations / s (whole call) and ms per iteration (steady state)."""
+    i mod world, ONE gather of the fitted parameters at the end of the fit).  `fit_many` itself reports how long its loop took;
+    the rest of the call is set-up (model objects, pipelines, plan creation, upload) and hand-back.
+    -> dict with sites x iterations / s (whole call) and ms per iteration (the training loop alone: `multisite_fit.LAST_TIMING`)."""
     from discontinuum_amd import multisite_fit
 
     def run(k):
@@ -376,17 +376,19 @@ def train_many(family, n, sites, iters, barrier=None, distributed=False):
             barrier()
         return time.perf_counter() - t0, objs
 
-    short = min(2, iters)
-    run(short)  # warm-up: code objects, allocator
-    t_short, _ = run(short)
+    run(min(2, iters))  # warm-up: code objects, allocator
     t_full, objs = run(iters)
-    per_it = (t_full - t_short) / (iters - short) if iters > short else t_full / max(1, iters)
+    tm = dict(multisite_fit.LAST_TIMING)  # this rank's fit_many: seconds before the first iteration / inside the loop
+    per_it = tm["loop_s"] / max(1, tm["iterations"])
+    local_sites = tm["sites"]
     return {"workload": f"{sites} {family}-gp sites of n={n} (d=2, fp64) trained for {iters} iterations by "
                         f"{'fit_many_distributed' if distributed else 'fit_many'} (labelled arrays in, fitted models out)",
             "sites": sites, "n": n, "iterations": iters, "seconds": t_full, "site_iterations_per_s": sites * iters / t_full,
-            "ms_per_iteration": per_it * 1e3, "site_iterations_per_s_steady": sites / per_it if per_it > 0 else None,
-            "setup_s": max(0.0, t_full - per_it * iters), "ok": bool(torch.isfinite(objs).all()),
-            "objective_mean": float(objs.mean())}
+            "ms_per_iteration": per_it * 1e3, "site_iterations_per_s_steady": local_sites / per_it if per_it > 0 else None,
+            "setup_s": t_full - tm["loop_s"], "closed_form_host_algebra": tm.get("closed_form"),
+            "timing_note": "ms_per_iteration = this rank's training loop / iterations (its share of the sites); seconds = the whole call "
+                           "incl. model objects, pipelines, plan creation, upload and -- distributed -- the final gather",
+            "ok": bool(torch.isfinite(objs).all()), "objective_mean": float(objs.mean())}
 
 
 def engine_iteration(family, n, iters):

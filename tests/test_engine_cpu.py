@@ -557,3 +557,54 @@ def test_fit_many_state_round_trips_through_weights_only_and_carries_the_nan_cou
             assert torch.equal(a, b), k
     old = {k: v for k, v in st.as_dict().items() if k != "nan_run"}
     assert torch.equal(FitManyState.from_dict(old).nan_run, torch.zeros(B, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("family", ["loadest", "rating"])
+def test_fit_many_closed_form_follows_the_autograd_trajectory(family, monkeypatch):
+    """``fit_many(closed_form=True)`` (the default: constraints, hyperparameter vectors, log-priors and the chain rule for all
+    sites as a dozen numpy operations on one (B, T) array, ``multisite_fit._ClosedForm``) against ``closed_form=False``
+    (``torch.func.vmap`` over the module trees + autograd) on the oracle-backed batched plan double: the same arithmetic
+    in a different order, so after 8 Adam iterations the raw parameters agree to 1e-12 and the objectives to 1e-12 relative;
+    a run split by ``return_state`` / ``resume`` (5 + 3) is bitwise the uninterrupted closed-form run, and the state it returns
+    has the named layout the autograd path's has.  Reference loop: /root/reference/src/discontinuum/engines/gpytorch.py:346-451."""
+    from discontinuum_amd import multisite_fit
+
+    monkeypatch.setattr(MarginalHIP, "_plan_factory", staticmethod(OraclePlan))
+    monkeypatch.setattr(MarginalHIP, "device", "cpu")
+    monkeypatch.setattr(multisite_fit, "GPPlan", OraclePlan)
+    sizes = (31, 44, 27, 38) if family == "loadest" else (33, 29, 41)
+
+    def sites():
+        if family == "loadest":
+            return [LoadestGP() for _ in sizes], [loadest_dataset(n, seed=10 + i) for i, n in enumerate(sizes)]
+        return [RatingGP() for _ in sizes], [rating_dataset(n, seed=20 + i) for i, n in enumerate(sizes)]
+
+    def flat(ms):
+        return torch.cat([p.detach().reshape(-1) for m in ms for _, p in sorted(m.model.named_parameters())]
+                         + [p.detach().reshape(-1) for m in ms for _, p in sorted(m.likelihood.named_parameters())])
+
+    seeds = list(range(len(sizes)))
+    used = []
+    real_build = multisite_fit._ClosedForm.build
+    monkeypatch.setattr(multisite_fit._ClosedForm, "build", classmethod(lambda cls, *a: used.append(real_build(*a)) or used[-1]))
+    ma, da = sites()
+    oa, sa = multisite_fit.fit_many(ma, da, iterations=8, site_seeds=seeds, return_state=True)
+    assert used and used[-1] is not None, "the shipped models must take the closed-form path"
+    mb, db = sites()
+    ob, sb = multisite_fit.fit_many(mb, db, iterations=8, site_seeds=seeds, closed_form=False, return_state=True)
+    assert len(used) == 1  # closed_form=False never builds it
+    assert (flat(ma) - flat(mb)).abs().max() <= 1e-12, (flat(ma) - flat(mb)).abs().max()
+    assert ((oa - ob).abs() / ob.abs()).max() <= 1e-12
+    assert set(sa.params) == set(sb.params) and all(sa.params[k].shape == sb.params[k].shape for k in sb.params)
+    assert all((sa.m1[k] - sb.m1[k]).abs().max() <= 1e-12 and (sa.m2[k] - sb.m2[k]).abs().max() <= 1e-12 for k in sb.m1)
+    # 5 + 3 iterations through a saved state = 8
+    mc, dc = sites()
+    _, st = multisite_fit.fit_many(mc, dc, iterations=5, site_seeds=seeds, return_state=True)
+    oc = multisite_fit.fit_many(mc, dc, iterations=3, site_seeds=seeds, resume=st)
+    assert torch.equal(flat(mc), flat(ma)) and torch.equal(oc, oa)
+    # a penalty term needs autograd: the closed form steps aside
+    md, dd = sites()
+    n_before = len(used)
+    multisite_fit.fit_many(md, dd, iterations=1, site_seeds=seeds, penalty_callback=lambda i, p: sum((v ** 2).sum() for v in p.values()),
+                           penalty_weight=0.1)
+    assert len(used) == n_before
