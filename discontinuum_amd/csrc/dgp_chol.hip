@@ -122,8 +122,15 @@ struct YieldHook {
     yield_refresh(word, (unsigned)(size_t)(dgp_lds_ptr)copy);
   }
 };
-// STREAM: the tile of C with non-temporal loads / stores (dgp_gemm.h::trailing_begin) -- the bulk update
-template <typename T, int BM, int BN, bool POLITE = false, bool STREAM = false, int RING = 3>
+#ifndef DGP_BULK_C_DEFAULT
+#define DGP_BULK_C_DEFAULT 0
+#endif
+#ifndef DGP_COL_C_DEFAULT
+#define DGP_COL_C_DEFAULT 0
+#endif
+// CMODE: how the tile of C moves (dgp_gemm.h::trailing_begin): bit 0 = non-temporal loads / stores (STREAM), bit 1 = 16-byte
+// accesses with a lane-pair swap (WIDE, fp64) -- the bulk update's tiles
+template <typename T, int BM, int BN, bool POLITE = false, int CMODE = 0, int RING = 3>
 __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int nk, long row0, long col0,
                                           T* __restrict__ smem, const unsigned* yield_word = nullptr, unsigned me = 0,
                                           const unsigned* yield_copy = nullptr) {
@@ -132,12 +139,13 @@ __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int
   typename G::acc_t acc[G::MI][G::NI];
   T* C = A + row0 * ld + col0;
   typename G::acc_t keep[G::MI][G::NI];
-  trailing_begin<T, G, K::DMA, STREAM>(acc, keep, C, ld);
+  constexpr bool STREAM = (CMODE & 1) != 0, WIDE = (CMODE & 2) != 0;
+  trailing_begin<T, G, K::DMA, STREAM, WIDE>(acc, keep, C, ld);
   if constexpr (POLITE)
     K::run_hooked(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc, YieldHook{yield_word, me, yield_copy});
   else
     K::run(A + row0 * ld + (long)k * NB, ld, A + col0 * ld + (long)k * NB, ld, nk * (NB / 16), smem, acc);
-  trailing_end<T, G, K::DMA, STREAM>(acc, keep, C, ld);
+  trailing_end<T, G, K::DMA, STREAM, WIDE>(acc, keep, C, ld);
 }
 
 // RING = 2 (experiment, DGP_BULK_RING=2 with the group panel solve): a 32 KB ring, so that a CU with three of these workgroups
@@ -145,7 +153,7 @@ __device__ __forceinline__ void syrk_tile(T* __restrict__ A, long ld, int k, int
 // BESIDE a bulk launch) would fit as soon as ONE of them retires.  Measured: it does not change when that kernel is placed --
 // the second diagonal block of a group still waits for the bulk launch to drain (2.9 ms at 64 x n = 4096 with either ring,
 // profiles/r05_experiments_group_gemm.txt), and two bulk workgroups per CU (DGP_BULK_PAD_BATCH) do not either
-template <typename T, bool POLITE = false, bool STREAM = false, int RING = 3>
+template <typename T, bool POLITE = false, int CMODE = 0, int RING = 3>
 __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kernel(T* __restrict__ A, long ld, int k, int nk, int jbeg, int nfull,
                                                                                    int split, long bs, int nt = 0, int super = 0,
                                                                                    const unsigned* yield_word = nullptr) {
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kern
     // all tiles cost the same: remap freely -- consecutive logical tiles on one XCD; `super` picks the logical order
     if (super > 0) super_decode(xcd_remap(b, nfull), nt, super, bi, bj);
     else tri_decode(xcd_remap(b, nfull), bi, bj);
-    syrk_tile<T, 128, 128, POLITE, STREAM, RING>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem, yield_word, POLITE ? cu_code() : 0u,
+    syrk_tile<T, 128, 128, POLITE, CMODE, RING>(A, ld, k, nk, (long)(bi + jbeg) * NB, (long)(bj + jbeg) * NB, smem, yield_word, POLITE ? cu_code() : 0u,
                                    yield_copy + (POLITE ? 64 * __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0));
     return;
   }
@@ -171,10 +179,10 @@ __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_kern
   const long row0 = (long)(bi + jbeg) * NB, col0 = (long)(bj + jbeg) * NB;
   const int part = sub % split;
   if (split == 2) {
-    syrk_tile<T, 64, 128, false, STREAM>(A, ld, k, nk, row0 + 64 * part, col0, smem);
+    syrk_tile<T, 64, 128, false, CMODE>(A, ld, k, nk, row0 + 64 * part, col0, smem);
   } else {
     if (bi == bj && part == 1) return;  // strictly upper quadrant of a diagonal tile
-    syrk_tile<T, 64, 64, false, STREAM>(A, ld, k, nk, row0 + 64 * (part >> 1), col0 + 64 * (part & 1), smem);
+    syrk_tile<T, 64, 64, false, CMODE>(A, ld, k, nk, row0 + 64 * (part >> 1), col0 + 64 * (part & 1), smem);
   }
 }
 
@@ -251,14 +259,14 @@ __global__ __launch_bounds__(256, 2) void syrk_col_kernel(T* __restrict__ A, lon
 
 // the same columns in 128 x 128 tiles of the direct-to-LDS core, for batched plans: there the group's column update is
 // thousands of tiles and not latency-critical (the sites fill each other's gaps); bitwise the same sums
-template <typename T, bool STREAM = false>
+template <typename T, int CMODE = 0>
 __global__ __launch_bounds__(256, (TileCore<T, true, true>::OCC)) void syrk_col128_kernel(T* __restrict__ A, long ld, int k, int nk, int jcol,
                                                                                           int nbk, int ncol, long bs) {
   __shared__ T smem[TileCore<T, true, true>::SMEM_ELEMS];
   A += (long)((int)blockIdx.z / ncol) * bs;
   const int jc = jcol + (int)blockIdx.z % ncol;
   if ((int)blockIdx.x >= nbk - jc) return;  // the later columns are shorter
-  syrk_tile<T, 128, 128, false, STREAM>(A, ld, k, nk, (long)(jc + (int)blockIdx.x) * NB, (long)jc * NB, smem);
+  syrk_tile<T, 128, 128, false, CMODE>(A, ld, k, nk, (long)(jc + (int)blockIdx.x) * NB, (long)jc * NB, smem);
 }
 
 // launch the LDS-resident diagonal-block kernel (needs > 64 KB of dynamic LDS: opt in once per instantiation).
@@ -307,31 +315,44 @@ static void launch_bulk(T* A, long N, int k, int nk, int jbeg, const SyrkShape& 
   static const int pad_env = getenv("DGP_BULK_LDS_PAD") ? std::min(16384, std::max(0, atoi(getenv("DGP_BULK_LDS_PAD")))) : 14336;
   // (batched plans: 64 x 4096 797 -> 789 fits/s, 32 x 8192 115.6 -> 115.0, 128 x 2048 no change -- their chain kernels are wide enough)
   const size_t pad = (bt.B == 1 && nbk >= 40 && nbk <= 160) ? (size_t)pad_env : 0;
-  // DGP_BULK_STREAM=1: the tiles of C through non-temporal loads / stores (dgp_gemm.h: STREAM).  A measurement knob, default
-  // off: the tile ALONE gains 7 % at K = 512 (65.3 -> 69.8 TFLOP/s, scripts/syrk_persist.hip), and in situ the bulk launches'
-  // sum drops 79.2 -> 75.7 ms at 32 x n = 8192 -- but the step does not move (275.6 / 275.9 ms; n = 32768 fp64 515.9 -> 513.5;
-  // fp32, whose tiles read C in the epilogue, loses: n = 16384 38.18 -> 38.70 ms): beside the chain's kernels the stalled
-  // cycles of a bulk workgroup were not idle cycles of the GPU (scripts/env_ab.py, one box, alternating processes)
-  static const bool stream = getenv("DGP_BULK_STREAM") ? atoi(getenv("DGP_BULK_STREAM")) != 0 : false;
+  // DGP_BULK_C: how the tiles of C move -- 0 plain 8-byte accesses (the form until round 4), 1 non-temporal, 2 16-byte accesses with
+  // a lane-pair swap (fp64), 3 both.  Measured on the tile alone (scripts/syrk_persist.hip, fp64, TFLOP/s at K = 512 / 256): 64.0 /
+  // 52.7, 68.6 / 60.9, 69.7 / 62.2, 70.6 / 64.1 -- the read-modify-write of C, not the dispatch or the ring fill, is what
+  // separates a short-K tile from the long-K rate (74.4 with no C traffic).  In situ every variant ties or LOSES (default 0):
+  // the non-temporal form moves the bulk launches' sum 79.2 -> 75.7 ms and the step not at all; the 16-byte form needs a
+  // lane-pair swap on 128 live accumulator registers, which this kernel (168 registers, 20 already spilled) only affords by
+  // spilling 99 registers around every tile (400 bytes of scratch per lane -- as much traffic as the tile itself): bulk sum
+  // 77.3 -> 82.4 ms, step 275.4 -> 280.2 (32 x n = 8192), 11.90 -> 12.55 ms (one site).  EXPERIMENTS.md round 5.
+  static const int cmode_env = getenv("DGP_BULK_C") ? atoi(getenv("DGP_BULK_C")) & 3 : DGP_BULK_C_DEFAULT;
+  const int cmode = sizeof(T) == 8 ? cmode_env : (cmode_env & 1);  // (fp32 tiles read C in the epilogue: no wide form)
   const unsigned* yw = reinterpret_cast<const unsigned*>(info + CHAIN_YIELD);
-  // batched plans on the group panel solve: the 32 KB ring (syrk_kernel: RING); DGP_BULK_RING=3 keeps the 48 KB one (A/B)
-  static const int ring_env = getenv("DGP_BULK_RING") ? atoi(getenv("DGP_BULK_RING")) : 3;  // (2: measured no different, below)
+  // batched plans on the group panel solve: the 32 KB ring (syrk_kernel: RING) when DGP_BULK_RING=2 (experiment)
+  static const int ring_env = getenv("DGP_BULK_RING") ? atoi(getenv("DGP_BULK_RING")) : 3;
   static const int pad_batch = getenv("DGP_BULK_PAD_BATCH") ? std::min(65536, std::max(0, atoi(getenv("DGP_BULK_PAD_BATCH")))) : 0;  // experiment
   if (bt.B >= 4 && bt.tuning().group_gemm && bt.W != nullptr && ring_env == 2) {
-    syrk_kernel<T, false, false, 2><<<grid, 256, (size_t)pad_batch, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
+    syrk_kernel<T, false, 0, 2><<<grid, 256, (size_t)pad_batch, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
     return;
   }
-  if (bt.B >= 4 && pad_batch > 0) {
-    syrk_kernel<T, false, false><<<grid, 256, (size_t)pad_batch, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
-    return;
-  }
+  const size_t lds_pad = (bt.B >= 4 && pad_batch > 0) ? (size_t)pad_batch : pad;
+#define DGP_LAUNCH_BULK(POLITE_, CM_)                                                                                              \
+  syrk_kernel<T, POLITE_, CM_><<<grid, 256, lds_pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, \
+                                                         POLITE_ ? yw : nullptr)
   if (yields(bt)) {
-    if (stream) syrk_kernel<T, true, true><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, yw);
-    else syrk_kernel<T, true, false><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, yw);
+    switch (cmode) {
+      case 1: DGP_LAUNCH_BULK(true, 1); break;
+      case 2: DGP_LAUNCH_BULK(true, 2); break;
+      case 3: DGP_LAUNCH_BULK(true, 3); break;
+      default: DGP_LAUNCH_BULK(true, 0);
+    }
   } else {
-    if (stream) syrk_kernel<T, false, true><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
-    else syrk_kernel<T, false, false><<<grid, 256, pad, s>>>(A, N, k, nk, jbeg, sh.nfull, sh.split, bt.ws, nt, bt.tuning().syrk_super, nullptr);
+    switch (cmode) {
+      case 1: DGP_LAUNCH_BULK(false, 1); break;
+      case 2: DGP_LAUNCH_BULK(false, 2); break;
+      case 3: DGP_LAUNCH_BULK(false, 3); break;
+      default: DGP_LAUNCH_BULK(false, 0);
+    }
   }
+#undef DGP_LAUNCH_BULK
 }
 template <typename TS, typename TC>
 static void launch_diag_as(TS* A, long N, long k0, TS* Tinv, TS* logdet, int* info, hipStream_t s, Batch bt, bool init,
@@ -467,10 +488,15 @@ int potrf(T* A, long N, T* Tinv, T* logdet, int* info, int lookahead, hipStream_
       if (q >= 1) {
         static const int col128 = getenv("DGP_COL128") ? atoi(getenv("DGP_COL128")) : 4;  // batch size from which the group's columns use 128-tiles
         if (bt.B >= col128) {
-          // DGP_COL_STREAM=1: the group's look-ahead column update with non-temporal accesses too (A/B; default plain)
-          static const bool cstream = getenv("DGP_COL_STREAM") ? atoi(getenv("DGP_COL_STREAM")) != 0 : false;
-          if (cstream) syrk_col128_kernel<T, true><<<dim3(nbk - k0, 1, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
-          else syrk_col128_kernel<T, false><<<dim3(nbk - k0, 1, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
+          // DGP_COL_C: the group's look-ahead column update likewise (its tiles ARE re-read soon, by the chain: only the wide form, 2, is a candidate)
+          static const int ccol = getenv("DGP_COL_C") ? atoi(getenv("DGP_COL_C")) & 3 : DGP_COL_C_DEFAULT;
+          const dim3 cgrid(nbk - k0, 1, ncol * Bz);
+          switch (sizeof(T) == 8 ? ccol : (ccol & 1)) {
+            case 1: syrk_col128_kernel<T, 1><<<cgrid, 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws); break;
+            case 2: syrk_col128_kernel<T, 2><<<cgrid, 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws); break;
+            case 3: syrk_col128_kernel<T, 3><<<cgrid, 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws); break;
+            default: syrk_col128_kernel<T, 0><<<cgrid, 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
+          }
         }
         else syrk_col_kernel<T><<<dim3(2 * (nbk - k0), 2, ncol * Bz), 256, 0, s>>>(A, N, k0 - G, G, k0, nbk, ncol, bt.ws);
       }

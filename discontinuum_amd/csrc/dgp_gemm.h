@@ -203,17 +203,97 @@ __device__ __forceinline__ void st_c(T* p, T v) {
   if constexpr (STREAM) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
-template <typename T, typename G, bool LATE = false, bool STREAM = false>
+// WIDE (round 5; fp64 tiles on the plain accumulator map): the tile of C moves in 16-BYTE accesses, half as many instructions.
+// In the accumulator layout of v_mfma_f64_16x16x4 a lane owns ONE column (lane & 15) of rows (lane >> 4) + 4 r, so its natural
+// access is 8 bytes; here the lanes of a pair (2 j, 2 j + 1) each fetch BOTH columns of two of the four rows (the even lane rows
+// r = 0, 2, the odd lane r = 1, 3 -- every wave instruction still covers whole 128-byte lines) and swap the halves they do not own
+// through a DPP quad permute (VALU, no LDS).  Pure data movement: bitwise the same tile.  Measured on the bulk tile alone
+// (scripts/syrk_persist.hip): K = 512 64.0 -> 69.7 TFLOP/s (with the non-temporal hint 70.6), K = 256 52.7 -> 62.2 (64.1).
+__device__ __forceinline__ double dpp_swap_pair(double v) {  // the value of lane ^ 1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// Both directions work IN PLACE on the accumulator registers (elements 2 h, 2 h + 1 of an accumulator are adjacent: a 16-byte
+// load lands in them directly, a 16-byte store reads them directly) and in two passes -- all loads, then all swaps; all swaps,
+// then all stores -- so that no load result needs a temporary: a first version that swapped per load made the compiler hold 32
+// loads' worth of temporaries beside the 128 accumulators (99 spilled registers, bulk update 6 % SLOWER in situ).
+// A lane's pair (x0, x1) = columns (2 j, 2 j + 1) of one row: the even lane keeps x0 and owes x1 to its partner, the odd lane
+// keeps x1 and owes x0; after the swap  acc[2 h] = even ? x0 : partner's x1,  acc[2 h + 1] = even ? partner's x0 : x1.
+template <typename G, bool NEGATE>
+__device__ __forceinline__ void tile_pair_swap(typename G::acc_t (&acc)[G::MI][G::NI], int p) {
+#pragma unroll
+  for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double x0 = acc[mi][ni][2 * h], x1 = acc[mi][ni][2 * h + 1];
+        const double got = dpp_swap_pair(p ? x0 : x1);
+        acc[mi][ni][2 * h] = NEGATE ? -(p ? got : x0) : (p ? got : x0);
+        acc[mi][ni][2 * h + 1] = NEGATE ? -(p ? x1 : got) : (p ? x1 : got);
+      }
+}
+template <typename G, bool STREAM, bool NEGATE>
+__device__ __forceinline__ void tile_load_wide(typename G::acc_t (&acc)[G::MI][G::NI], const double* __restrict__ C, long ld) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, p = lane & 1;
+  const double* base = C + (long)((w >> 1) * (16 * G::MI) + (lane >> 4) + 4 * p) * ld + (w & 1) * (16 * G::NI) + ((lane & 15) & ~1);
+#pragma unroll
+  for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const dgp_d2* src = reinterpret_cast<const dgp_d2*>(base + (long)(mi * 16 + 8 * h) * ld + ni * 16);
+        const dgp_d2 v = STREAM ? __builtin_nontemporal_load(src) : *src;
+        acc[mi][ni][2 * h] = v[0];
+        acc[mi][ni][2 * h + 1] = v[1];
+      }
+  tile_pair_swap<G, NEGATE>(acc, p);
+}
+// (destroys acc: the tile's last use)
+template <typename G, bool STREAM, bool NEGATE>
+__device__ __forceinline__ void tile_store_wide(typename G::acc_t (&acc)[G::MI][G::NI], double* __restrict__ C, long ld) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, p = lane & 1;
+  double* base = C + (long)((w >> 1) * (16 * G::MI) + (lane >> 4) + 4 * p) * ld + (w & 1) * (16 * G::NI) + ((lane & 15) & ~1);
+  // the inverse exchange: the even lane owes acc[2 h + 1] (its column of row r = 2 h + 1, which the odd lane stores), the odd lane
+  // acc[2 h]; afterwards (acc[2 h], acc[2 h + 1]) = the two columns of the row this lane stores
+#pragma unroll
+  for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double a0 = acc[mi][ni][2 * h], a1 = acc[mi][ni][2 * h + 1];
+        const double got = dpp_swap_pair(p ? a0 : a1);
+        acc[mi][ni][2 * h] = NEGATE ? -(p ? got : a0) : (p ? got : a0);
+        acc[mi][ni][2 * h + 1] = NEGATE ? -(p ? a1 : got) : (p ? a1 : got);
+      }
+#pragma unroll
+  for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const dgp_d2 v = {acc[mi][ni][2 * h], acc[mi][ni][2 * h + 1]};
+        dgp_d2* dst = reinterpret_cast<dgp_d2*>(base + (long)(mi * 16 + 8 * h) * ld + ni * 16);
+        if (STREAM) __builtin_nontemporal_store(v, dst);
+        else *dst = v;
+      }
+}
+template <typename T, typename G, bool LATE = false, bool STREAM = false, bool WIDE = false>
 __device__ __forceinline__ void trailing_begin(typename G::acc_t (&acc)[G::MI][G::NI], typename G::acc_t (&keep)[G::MI][G::NI],
                                                const T* __restrict__ C, long ld) {
   if (sizeof(T) == 4) {
     if (!LATE) G::foreach (keep, [&](int r, int c, T& v) { v = ld_c<STREAM>(&C[(long)r * ld + c]); });
     G::zero(acc);
   } else {
-    G::foreach (acc, [&](int r, int c, T& v) { v = -ld_c<STREAM>(&C[(long)r * ld + c]); });
+    if constexpr (WIDE && sizeof(T) == 8) tile_load_wide<G, STREAM, true>(acc, (const double*)C, ld);
+    else G::foreach (acc, [&](int r, int c, T& v) { v = -ld_c<STREAM>(&C[(long)r * ld + c]); });
   }
 }
-template <typename T, typename G, bool LATE = false, bool STREAM = false>
+template <typename T, typename G, bool LATE = false, bool STREAM = false, bool WIDE = false>
 __device__ __forceinline__ void trailing_end(typename G::acc_t (&acc)[G::MI][G::NI], typename G::acc_t (&keep)[G::MI][G::NI],
                                              T* __restrict__ C, long ld) {
   if (sizeof(T) == 4 && LATE) {
@@ -228,7 +308,8 @@ __device__ __forceinline__ void trailing_end(typename G::acc_t (&acc)[G::MI][G::
         for (int r = 0; r < 4; ++r) acc[mi][ni][r] = keep[mi][ni][r] - acc[mi][ni][r];
     G::foreach (acc, [&](int r, int c, T& v) { st_c<STREAM>(&C[(long)r * ld + c], v); });
   } else {
-    G::foreach (acc, [&](int r, int c, T& v) { st_c<STREAM>(&C[(long)r * ld + c], T(-v)); });
+    if constexpr (WIDE && sizeof(T) == 8) tile_store_wide<G, STREAM, true>(acc, (double*)C, ld);
+    else G::foreach (acc, [&](int r, int c, T& v) { st_c<STREAM>(&C[(long)r * ld + c], T(-v)); });
   }
 }
 

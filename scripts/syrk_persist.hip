@@ -29,9 +29,43 @@ __device__ __forceinline__ void one_tile(T* A, long ld, int nk, int bi, int bj, 
   // it need not displace the operand panels from L2); 5: non-temporal loads only; 6: non-temporal stores only
   if (CIO == 3 || CIO == 1 || CIO == 6) trailing_begin<T, G, K::DMA>(acc, keep, C, ld);
   else if (CIO == 4 || CIO == 5) G::foreach (acc, [&](int r, int c, T& v) { v = -__builtin_nontemporal_load(&C[(long)r * ld + c]); });
-  else G::zero(acc);
+  else if (CIO == 7 || CIO == 8 || CIO == 9) {
+    // TIMING ONLY (values land in the wrong accumulator slots): the tile of C through 16-byte loads / stores, half as many
+    // instructions -- lane l covers row (l >> 3) + 8 p of its wave's 64 x 64 quadrant, columns 8 q + 2 (l & 7) .. + 1
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const T* Cq = C + (long)((w >> 1) * 64) * ld + (w & 1) * 64;
+#pragma unroll
+    for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int slab = (mi * G::NI + ni) * 2 + h;  // 32 slabs of 8 rows x 16 columns... laid out as 8 rows x 64 columns / 4
+          const long r = (slab >> 2) * 8 + (lane >> 3), c = (slab & 3) * 16 + 2 * (lane & 7);
+          const dgp_d2 v = CIO == 9 ? __builtin_nontemporal_load(reinterpret_cast<const dgp_d2*>(Cq + r * ld + c)) : *reinterpret_cast<const dgp_d2*>(Cq + r * ld + c);
+          acc[mi][ni][2 * h] = -v[0];
+          acc[mi][ni][2 * h + 1] = -v[1];
+        }
+  } else G::zero(acc);
   K::run(A + row0 * ld, ld, A + col0 * ld, ld, nk * (NB / 16), smem, acc);
-  if (CIO == 2 || CIO == 3 || CIO == 5) trailing_end<T, G, K::DMA>(acc, keep, C, ld);
+  if (CIO == 8 || CIO == 9) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T* Cq = C + (long)((w >> 1) * 64) * ld + (w & 1) * 64;
+#pragma unroll
+    for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int slab = (mi * G::NI + ni) * 2 + h;
+          const long r = (slab >> 2) * 8 + (lane >> 3), c = (slab & 3) * 16 + 2 * (lane & 7);
+          dgp_d2 v = {-acc[mi][ni][2 * h], -acc[mi][ni][2 * h + 1]};
+          if (CIO == 9) __builtin_nontemporal_store(v, reinterpret_cast<dgp_d2*>(Cq + r * ld + c));
+          else *reinterpret_cast<dgp_d2*>(Cq + r * ld + c) = v;
+        }
+    return;
+  }
+  if (CIO == 2 || CIO == 3 || CIO == 5 || CIO == 7) trailing_end<T, G, K::DMA>(acc, keep, C, ld);
   else if (CIO == 4 || CIO == 6) G::foreach (acc, [&](int r, int c, T& v) { __builtin_nontemporal_store(-v, &C[(long)r * ld + c]); });
   else {
     T sum = T(0);
@@ -86,7 +120,7 @@ int main(int argc, char** argv) {
     if (mode == 0) syrk_bench_kernel<double, 0, CIO_><<<ntiles, 256>>>(A, N, nk, ntiles);       \
     else syrk_bench_kernel<double, 1, CIO_><<<grid, 256>>>(A, N, nk, ntiles);                   \
   }
-        LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6)
+        LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9)
       }
       hipEventRecord(e1);
       hipEventSynchronize(e1);
@@ -97,7 +131,7 @@ int main(int argc, char** argv) {
     return best / 4.0;
   };
   const int maxmode = getenv("PERSIST") ? 2 : 1;
-  for (int cio : {3, 4, 5, 6, 2, 1, 0})
+  for (int cio : {3, 7, 8, 9, 4, 5, 6, 2, 1, 0})
     for (int mode = 0; mode < maxmode; ++mode) {
       const double ms = timeit(mode, cio);
       printf("MODE %d CIO %d  nt=%d (%d tiles) K=%d grid=%d: %.3f ms  %.2f TFLOP/s\n", mode, cio, nt, ntiles, nk * NB, mode ? grid : ntiles, ms,
