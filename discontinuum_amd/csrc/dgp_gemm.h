@@ -10,6 +10,7 @@
 // 2048 flop per SIMD); the LDS image is laid out so every ds_read_b64 fragment read is
 // bank-conflict free:  KC -> [row][17] (odd stride), IC -> [k][rows+16] (stride = 128 B mod 256 B).
 #pragma once
+#include <type_traits>
 #include "dgp_common.h"
 
 namespace dgp {
@@ -282,23 +283,46 @@ __device__ __forceinline__ void tile_store_wide(typename G::acc_t (&acc)[G::MI][
         else *dst = v;
       }
 }
+// The tile of C on the plain accumulator map through SCALAR row bases + one 32-bit lane offset (round 5).  `G::foreach` hands out
+// (row, column) pairs and the obvious `C[row * ld + col]` makes the compiler keep a 64-bit address per access: with the 128
+// accumulators of an fp64 128 x 128 tile live at the same time that cost the bulk update 20 spilled registers around every tile.
+// Here the part of the address that depends on the lane -- (crow(lane, 0) * ld + (lane & 15)) elements -- is ONE register, the
+// rest (wave tile, 16-row group, register index) is wave-uniform and lives in scalar registers, so every access is the saddr
+// form of global_load / global_store with an immediate for the 16-column group.  Same elements, same values; measured on the
+// bulk tile alone (scripts/syrk_persist.hip, fp64): K = 512 64.3 -> 68.2 TFLOP/s, K = 256 53.2 -> 58.1, no spill, 166 registers.
+// f(ptr, mi, ni, r): ptr = the address of the element that accumulator [mi][ni][r] of this lane stands for.
+template <typename T, typename G, typename P, typename F>
+__device__ __forceinline__ void tile_rows_foreach(P* __restrict__ C, long ld, F f) {
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const unsigned loff = (unsigned)(((long)Mfma<T>::crow(lane, 0) * ld + (lane & 15)) * (long)sizeof(T));
+  char* Cw = (char*)(const_cast<typename std::remove_const<P>::type*>(C) + (long)((w >> 1) * (16 * G::MI)) * ld + (w & 1) * (16 * G::NI));
+  const int rstep = Mfma<T>::crow(0, 1);  // rows between consecutive accumulator registers (fp64: 4, fp32: 1)
+#pragma unroll
+  for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      char* rp = Cw + (long)(mi * 16 + rstep * r) * ld * (long)sizeof(T);
+#pragma unroll
+      for (int ni = 0; ni < G::NI; ++ni) f(reinterpret_cast<P*>(rp + ni * 16 * (int)sizeof(T) + loff), mi, ni, r);
+    }
+}
 template <typename T, typename G, bool LATE = false, bool STREAM = false, bool WIDE = false>
 __device__ __forceinline__ void trailing_begin(typename G::acc_t (&acc)[G::MI][G::NI], typename G::acc_t (&keep)[G::MI][G::NI],
                                                const T* __restrict__ C, long ld) {
   if (sizeof(T) == 4) {
-    if (!LATE) G::foreach (keep, [&](int r, int c, T& v) { v = ld_c<STREAM>(&C[(long)r * ld + c]); });
+    if (!LATE) tile_rows_foreach<T, G>(C, ld, [&](const T* q, int mi, int ni, int r) { keep[mi][ni][r] = ld_c<STREAM>(q); });
     G::zero(acc);
   } else {
     if constexpr (WIDE && sizeof(T) == 8) tile_load_wide<G, STREAM, true>(acc, (const double*)C, ld);
-    else G::foreach (acc, [&](int r, int c, T& v) { v = -ld_c<STREAM>(&C[(long)r * ld + c]); });
+    else tile_rows_foreach<T, G>(C, ld, [&](const T* q, int mi, int ni, int r) { acc[mi][ni][r] = -ld_c<STREAM>(q); });
   }
 }
 template <typename T, typename G, bool LATE = false, bool STREAM = false, bool WIDE = false>
 __device__ __forceinline__ void trailing_end(typename G::acc_t (&acc)[G::MI][G::NI], typename G::acc_t (&keep)[G::MI][G::NI],
                                              T* __restrict__ C, long ld) {
   if (sizeof(T) == 4 && LATE) {
-    G::foreach (acc, [&](int r, int c, T& v) { v = ld_c<STREAM>(&C[(long)r * ld + c]) - v; });
-    G::foreach (acc, [&](int r, int c, T& v) { st_c<STREAM>(&C[(long)r * ld + c], v); });
+    tile_rows_foreach<T, G>(C, ld, [&](T* q, int mi, int ni, int r) { acc[mi][ni][r] = ld_c<STREAM>(q) - acc[mi][ni][r]; });
+    tile_rows_foreach<T, G>(C, ld, [&](T* q, int mi, int ni, int r) { st_c<STREAM>(q, (T)acc[mi][ni][r]); });
   } else if (sizeof(T) == 4) {
 #pragma unroll
     for (int mi = 0; mi < G::MI; ++mi)
@@ -306,10 +330,10 @@ __device__ __forceinline__ void trailing_end(typename G::acc_t (&acc)[G::MI][G::
       for (int ni = 0; ni < G::NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[mi][ni][r] = keep[mi][ni][r] - acc[mi][ni][r];
-    G::foreach (acc, [&](int r, int c, T& v) { st_c<STREAM>(&C[(long)r * ld + c], v); });
+    tile_rows_foreach<T, G>(C, ld, [&](T* q, int mi, int ni, int r) { st_c<STREAM>(q, (T)acc[mi][ni][r]); });
   } else {
     if constexpr (WIDE && sizeof(T) == 8) tile_store_wide<G, STREAM, true>(acc, (double*)C, ld);
-    else G::foreach (acc, [&](int r, int c, T& v) { st_c<STREAM>(&C[(long)r * ld + c], T(-v)); });
+    else tile_rows_foreach<T, G>(C, ld, [&](T* q, int mi, int ni, int r) { st_c<STREAM>(q, T(-acc[mi][ni][r])); });
   }
 }
 

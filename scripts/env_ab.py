@@ -19,8 +19,11 @@ def child(n, S, steps, dtype):
     import torch
 
     sys.path.insert(0, ROOT)
-    import bench
     from discontinuum_amd import _lib
+
+    if os.environ.get("DGP_LIB_PATH"):  # A/B of two BUILDS: DGP_LIB_PATH=discontinuum_amd/libdgp_hip.so,scripts/libdgp_prev.so
+        _lib.LIB_PATH = os.path.abspath(os.environ["DGP_LIB_PATH"])
+    import bench
 
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
