@@ -693,13 +693,16 @@ static int run_grad(dgp_plan* p, const double* theta, void* dtheta, hipStream_t 
 // (scripts/env_ab.py, wall ms per step, 0 / 1 / 2): 32 x n = 8192 274.3 / 273.8 / 274.4 (lauum itself 81.0 -> 83.3 with the
 // solves beside it: its three workgroups per CU leave a trmv wave no registers, so the solves take slots, not idle
 // resources), 64 x n = 4096 80.56 / 79.30 / 79.59 (-1.6 %), one site n = 8192 11.85 / 11.84 / 11.81; bitwise the same results.
-// By default only for N <= 6144: at the headline size the step gains 0.2 % (below the 1 % bar) while lauum -- the kernel the
+// By default only for 1024 <= N <= 6144: at the headline size the step gains 0.2 % (below the 1 % bar) while lauum -- the kernel the
 // roofline is quoted on -- reads 3-4 % slower for sharing the GPU (84.8 against 82.4 ms alone, profiles/r05_lauum_three_ways.txt);
 // an explicit DGP_SOLVE_OVERLAP applies to every size.
 template <typename T>
 static int solve_overlap_mode(dgp_plan* p, hipStream_t s, hipStream_t* out) {
   static const int env = getenv("DGP_SOLVE_OVERLAP") ? atoi(getenv("DGP_SOLVE_OVERLAP")) : -1;
-  const int mode = env >= 0 ? env : (p->N <= 6144 ? 1 : 0);
+  // (and not below N = 1024: at the reference's own site size, n = 300, the step is ~0.3 ms of launches and the two cross-stream
+  // dependencies cost more than the overlap gains: 0.306 -> 0.334 ms; n = 1024 0.705 -> 0.681, 2048 1.319 -> 1.270,
+  // 128 x n = 2048 26.24 -> 25.62)
+  const int mode = env >= 0 ? env : ((p->N >= 1024 && p->N <= 6144) ? 1 : 0);
   if (mode <= 0 || !p->lookahead || !p->ev || p->nev < 2) return 0;
   if (sizeof(T) == 4 && p->refine) return 0;
   if (mode == 1 && p->s2) {

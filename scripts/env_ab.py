@@ -23,6 +23,11 @@ def child(n, S, steps, dtype):
 
     if os.environ.get("DGP_LIB_PATH"):  # A/B of two BUILDS: DGP_LIB_PATH=discontinuum_amd/libdgp_hip.so,scripts/libdgp_prev.so
         _lib.LIB_PATH = os.path.abspath(os.environ["DGP_LIB_PATH"])
+        import ctypes
+
+        probe = ctypes.CDLL(_lib.LIB_PATH)  # an older build may lack entry points added since: bind what it has
+        for name in [k for k in _lib.SIGNATURES if not hasattr(probe, k)]:
+            del _lib.SIGNATURES[name]
     import bench
 
     dev = torch.device("cuda:0")
