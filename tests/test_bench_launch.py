@@ -79,3 +79,41 @@ def test_plain_gpus_2_config5(gpu_device):
     assert len(lines) == 1, run.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["config"]["info"] == 0 and rec["config"]["backend"] == "gloo"
+
+
+def test_roofline_check_puts_the_three_figures_side_by_side(tmp_path):
+    """scripts/roofline_check.py on a synthetic collection: tracer launches from the kernel trace (the fit steps' first, not the
+    clock probe's loop behind them), the traced process's own HIP events, the counter pass and the bench line -> the table and
+    `lauum_three_ways.json` with `frac` recomputed from the profile and its agreement with the line."""
+    import csv
+
+    out = tmp_path / "prof"
+    out.mkdir()
+    flops = 32 * 8192.0 ** 3 / 3.0
+    with open(out / "kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        w.writerow(["void dgp::lauum_kernel<double>(double const*, double*, long, int, long, int)", 6, 6 * 81e6, 81.5e6, 24.0, 80e6, 83e6, 1.0])
+    trace = out / "trace.csv"
+    with open(trace, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        t = 0
+        for k, dur in enumerate((80.0e6, 80.2e6, 79.8e6, 80.0e6, 83e6, 83e6)):  # four fit steps, then the probe's loop
+            w.writerow(["void dgp::lauum_kernel<double>(double const*, double*, long, int, long, int)", t, int(t + dur)])
+            t += int(dur) + 1000
+        w.writerow(["void dgp::gram_sym_kernel<double>()", t, t + 10])
+    json.dump({"lauum_flops": flops, "lauum_ms_per_step": [80.01, 80.19, 79.81, 80.0], "lauum_clock": {"mhz": 2350.0}}, open(out / "stats_stdout.json", "w"))
+    json.dump({"lauum_kernel<double>": {"total_ms": 240.3, "launches": 3, "effective_clock_mhz": 2340.0, "mfma_busy_fraction": 0.96}},
+              open(out / "mfma_busy.json", "w"))
+    frac_line = flops / 80.4e-3 / 1e12 / 78.6
+    json.dump({"value": 116.0, "roofline": {"ms_per_step": 80.4, "frac": frac_line, "clock_mhz": 2360.0, "frac_at_clock": frac_line * 2400 / 2360.0,
+                                           "kernel": "lauum_kernel"}}, open(out / "bench_line.json", "w"))
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "roofline_check.py"), str(out), str(trace)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    res = json.load(open(out / "lauum_three_ways.json"))
+    s = res["stats_pass"]
+    assert s["tracer_ms_per_step"] == [80.0, 80.2, 79.8, 80.0] and abs(s["tracer_avg_ms"] - 80.0) < 1e-9  # not the 83 ms of the probe's loop
+    assert abs(s["tracer_minus_events_rel"]) < 1e-3 and abs(s["frac_from_tracer"] - flops / 80.0e-3 / 1e12 / 78.6) < 1e-12
+    assert abs(res["counter_pass"]["tracer_avg_ms"] - 80.1) < 1e-9 and abs(res["agreement"]["frac_tracer_vs_line_rel"] - (80.4 / 80.0 - 1)) < 1e-9
+    assert "agreement" in run.stdout and "tracer - events" in run.stdout
