@@ -70,9 +70,13 @@ def _worker(rank, world, port, q, family, sizes, mode):
             multisite_fit.fit_many = boom
         try:
             objs, table = multisite_fit.fit_many_distributed(models, data, iterations=ITERS, early_stopping=(mode == "early"),
-                                                             patience=2 if mode == "early" else 60)
+                                                             patience=2 if mode == "early" else 60,
+                                                             load=mode[5:] if mode.startswith("load=") else "all")
         except RuntimeError as e:
             q.put((rank, "error", str(e)))
+            return
+        if mode.startswith("load="):  # who holds which fitted site
+            q.put((rank, "ok", {"table": table.numpy(), "fitted": [bool(m.is_fitted) for m in models]}))
             return
         other = 1 if rank == 0 else 0  # a site this rank did NOT train
         mu, se = models[other].predict(data[other][0])
@@ -149,6 +153,16 @@ def test_a_rank_without_sites_takes_part():
     res = _run(3, "loadest", SIZES[:2])
     assert all(kind == "ok" for kind, _ in res.values()), res
     assert np.array_equal(res[0][1]["table"], res[2][1]["table"]) and res[2][1]["fitted"] == [True, True]
+
+
+def test_load_modes_decide_who_holds_the_other_ranks_sites():
+    """`load="rank0"`: only rank 0 loads the sites it did not train; `load="own"`: nobody does -- the table is gathered everywhere."""
+    res = _run(2, "loadest", SIZES[:3], mode="load=rank0")
+    assert res[0][1]["fitted"] == [True, True, True] and res[1][1]["fitted"] == [False, True, False]
+    assert np.array_equal(res[0][1]["table"], res[1][1]["table"])
+    res = _run(2, "loadest", SIZES[:3], mode="load=own")
+    assert res[0][1]["fitted"] == [True, False, True] and res[1][1]["fitted"] == [False, True, False]
+    assert np.array_equal(res[0][1]["table"], res[1][1]["table"]) and np.isfinite(res[0][1]["table"]).all()
 
 
 def test_without_a_process_group_it_is_fit_many(monkeypatch):
