@@ -31,6 +31,8 @@ of the fit"); the reference's fan-out is ``examples/nwqn-loadest-example/nwqn-lo
 """
 from __future__ import annotations
 
+import time
+
 import torch
 from torch import nn
 from torch.func import functional_call, vmap
@@ -446,9 +448,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     sites were built before it; with them it depends on the site alone (``fit_many_distributed`` relies on that)."""
     if site_seeds is not None and len(site_seeds) != len(models):
         raise ValueError("site_seeds needs one seed per model")
-    import time as _t0
-
-    t_enter = _t0.perf_counter()
+    t_enter = time.perf_counter()
     if optimizer not in ("adam", "adamw"):
         raise ValueError(f"Unsupported optimizer: {optimizer!r}. Supported optimizers are 'adam' and 'adamw'.")
     if len(models) != len(datasets) or not models:
@@ -609,9 +609,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     # for the loop; the caller's setting is restored behind it.
     host_threads = torch.get_num_threads()
     torch.set_num_threads(1)
-    import time as _time
-
-    t_loop = _time.perf_counter()
+    t_loop = time.perf_counter()
     it = it0 - 1  # (iterations = 0: nothing runs)
     try:
         for it in range(it0, it0 + iterations):
@@ -729,7 +727,7 @@ def fit_many(models, datasets, iterations: int = 100, learning_rate: float = 0.0
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     # diagnostics of the last call (bench.py reads them): seconds from entry to the first iteration, seconds in the loop
-    LAST_TIMING.update(setup_s=t_loop - t_enter, loop_s=_time.perf_counter() - t_loop, iterations=it - it0 + 1, sites=B,
+    LAST_TIMING.update(setup_s=t_loop - t_enter, loop_s=time.perf_counter() - t_loop, iterations=it - it0 + 1, sites=B,
                        closed_form=cf is not None)
 
     if cf is not None:  # back to the named, stacked form (hand-back, FitManyState)
